@@ -1,0 +1,30 @@
+# Builds the product library (HIP kernels + C ABI) for gfx950 and the CPU oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+CSRC := bio_amd/csrc
+LIB := bio_amd/lib/libbioalign.so
+OBJS := build/kernels.o build/api.o
+
+all: $(LIB) oracle
+
+$(LIB): $(OBJS)
+	@mkdir -p bio_amd/lib
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+
+build/kernels.o: $(CSRC)/kernels.hip $(CSRC)/common.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+build/api.o: $(CSRC)/api.cpp $(CSRC)/common.h include/bioalign.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -x hip -c -o $@ $<
+
+oracle:
+	$(MAKE) -C oracle libbio_oracle.so
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,257 @@
+"""ctypes binding of the C ABI in include/bioalign.h (bio_amd/lib/libbioalign.so).
+
+There is no fallback of any kind: if the HIP library is missing or no GPU is
+usable, importing works but every alignment call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbioalign.so")
+
+GLOBAL, LOCAL, FITTING, OVERLAP = 0, 1, 2, 3
+MODES = {"global": GLOBAL, "local": LOCAL, "fitting": FITTING, "overlap": OVERLAP}
+SCORE_ONLY = 1
+EINVAL, ENODEVICE, ENOMEM, EHIP, EUNSUPPORTED = -1, -2, -3, -4, -5
+
+# every symbol include/bioalign.h declares
+EXPORTS = (
+    "bioalign_abi_version",
+    "bioalign_create",
+    "bioalign_destroy",
+    "bioalign_last_error",
+    "bioalign_device_count",
+    "bioalign_batch",
+    "bioalign_plan_create",
+    "bioalign_plan_destroy",
+    "bioalign_plan_workspace_bytes",
+    "bioalign_plan_cells",
+    "bioalign_plan_run",
+    "bioalign_plan_last_dp_ms",
+)
+
+
+class BioAlignError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"bioalign error {code}: {msg}")
+        self.code = code
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("s1", C.c_void_p),
+        ("s1_off", C.c_void_p),
+        ("s2", C.c_void_p),
+        ("s2_off", C.c_void_p),
+        ("n_pairs", C.c_uint64),
+        ("mode", C.c_int32),
+        ("score_table", C.c_void_p),
+        ("na", C.c_int32),
+        ("nb", C.c_int32),
+        ("code1", C.c_void_p),
+        ("code2", C.c_void_p),
+        ("gap_open", C.c_int32),
+        ("gap_extend", C.c_int32),
+        ("gap_symbol", C.c_uint8),
+        ("flags", C.c_uint32),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("scores", C.c_void_p),
+        ("t1", C.c_void_p),
+        ("t2", C.c_void_p),
+        ("t_off", C.c_void_p),
+        ("t_len", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP library; raises (loudly) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950); "
+                "bio_amd has no CPU fallback"
+            )
+        L = C.CDLL(LIB_PATH)
+        L.bioalign_abi_version.restype = C.c_int
+        L.bioalign_create.restype = C.c_void_p
+        L.bioalign_create.argtypes = [C.POINTER(C.c_int), C.c_int]
+        L.bioalign_destroy.argtypes = [C.c_void_p]
+        L.bioalign_last_error.restype = C.c_char_p
+        L.bioalign_last_error.argtypes = [C.c_void_p]
+        L.bioalign_device_count.restype = C.c_int
+        L.bioalign_device_count.argtypes = [C.c_void_p]
+        L.bioalign_batch.restype = C.c_int
+        L.bioalign_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Result)]
+        L.bioalign_plan_create.restype = C.c_void_p
+        L.bioalign_plan_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(Batch)]
+        L.bioalign_plan_destroy.argtypes = [C.c_void_p]
+        L.bioalign_plan_workspace_bytes.restype = C.c_uint64
+        L.bioalign_plan_workspace_bytes.argtypes = [C.c_void_p]
+        L.bioalign_plan_cells.restype = C.c_uint64
+        L.bioalign_plan_cells.argtypes = [C.c_void_p]
+        L.bioalign_plan_run.restype = C.c_int
+        L.bioalign_plan_run.argtypes = [C.c_void_p] + [C.c_void_p] * 9 + [C.c_void_p]
+        L.bioalign_plan_last_dp_ms.restype = C.c_int
+        L.bioalign_plan_last_dp_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data if a is not None and a.size else 0
+
+
+class PackedBatch:
+    """Host-side batch in the C ABI's layout; keeps every numpy buffer alive."""
+
+    def __init__(self, s1, s1_off, s2, s2_off, mode, score_table, code1, code2,
+                 gap_open, gap_extend, gap_symbol=ord("-"), flags=0):
+        self.s1 = np.ascontiguousarray(s1, dtype=np.uint8)
+        self.s2 = np.ascontiguousarray(s2, dtype=np.uint8)
+        self.s1_off = np.ascontiguousarray(s1_off, dtype=np.uint64)
+        self.s2_off = np.ascontiguousarray(s2_off, dtype=np.uint64)
+        self.table = np.ascontiguousarray(score_table, dtype=np.int32)
+        if self.table.ndim != 2:
+            raise ValueError("score_table must be 2-D [na, nb]")
+        self.code1 = np.ascontiguousarray(code1, dtype=np.uint8)
+        self.code2 = np.ascontiguousarray(code2, dtype=np.uint8)
+        if self.code1.size != 256 or self.code2.size != 256:
+            raise ValueError("code maps must have 256 entries")
+        if len(self.s1_off) != len(self.s2_off) or len(self.s1_off) < 1:
+            raise ValueError("offset arrays must have n_pairs+1 entries each")
+        self.n_pairs = len(self.s1_off) - 1
+        self.mode = MODES[mode] if isinstance(mode, str) else int(mode)
+        # 1-byte placeholders so that empty inputs still pass non-null pointers
+        self._e = np.zeros(1, dtype=np.uint8)
+        b = Batch()
+        b.s1 = _ptr(self.s1) or self._e.ctypes.data
+        b.s2 = _ptr(self.s2) or self._e.ctypes.data
+        b.s1_off = self.s1_off.ctypes.data
+        b.s2_off = self.s2_off.ctypes.data
+        b.n_pairs = self.n_pairs
+        b.mode = self.mode
+        b.score_table = self.table.ctypes.data
+        b.na, b.nb = self.table.shape
+        b.code1 = self.code1.ctypes.data
+        b.code2 = self.code2.ctypes.data
+        b.gap_open = int(gap_open)
+        b.gap_extend = int(gap_extend)
+        b.gap_symbol = int(gap_symbol)
+        b.flags = int(flags)
+        self.c = b
+
+    @property
+    def trace_capacity(self) -> int:
+        return int(self.s1_off[-1] + self.s2_off[-1])
+
+
+class Engine:
+    """Owns a bioalign_ctx."""
+
+    def __init__(self, device_ids=None):
+        L = lib()
+        if device_ids:
+            arr = (C.c_int * len(device_ids))(*device_ids)
+            h = L.bioalign_create(arr, len(device_ids))
+        else:
+            h = L.bioalign_create(None, 0)
+        if not h:
+            raise BioAlignError(ENODEVICE, L.bioalign_last_error(None).decode())
+        self._h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().bioalign_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _raise(self, code: int):
+        raise BioAlignError(code, lib().bioalign_last_error(self._h).decode())
+
+    def device_count(self) -> int:
+        return lib().bioalign_device_count(self._h)
+
+    def batch(self, pb: PackedBatch):
+        """bioalign_batch on host buffers -> (scores, t1, t2, t_off, t_len)."""
+        n = pb.n_pairs
+        scores = np.zeros(max(n, 1), dtype=np.int64)
+        score_only = bool(pb.c.flags & SCORE_ONLY)
+        cap = pb.trace_capacity
+        t1 = np.zeros(cap + 1, dtype=np.uint8)
+        t2 = np.zeros(cap + 1, dtype=np.uint8)
+        t_off = np.zeros(max(n, 1), dtype=np.uint64)
+        t_len = np.zeros(max(n, 1), dtype=np.uint64)
+        r = Result()
+        r.scores = scores.ctypes.data
+        if not score_only:
+            r.t1, r.t2 = t1.ctypes.data, t2.ctypes.data
+            r.t_off, r.t_len = t_off.ctypes.data, t_len.ctypes.data
+        rc = lib().bioalign_batch(self._h, C.byref(pb.c), C.byref(r))
+        if rc != 0:
+            self._raise(rc)
+        return scores[:n], t1, t2, t_off[:n], t_len[:n]
+
+    def plan(self, pb: PackedBatch, device_index: int = 0) -> "Plan":
+        return Plan(self, pb, device_index)
+
+
+class Plan:
+    """Owns a bioalign_plan (device workspace + bundle tables)."""
+
+    def __init__(self, engine: Engine, pb: PackedBatch, device_index: int = 0):
+        self.engine = engine
+        h = lib().bioalign_plan_create(engine._h, device_index, C.byref(pb.c))
+        if not h:
+            raise BioAlignError(EINVAL, lib().bioalign_last_error(engine._h).decode())
+        self._h = C.c_void_p(h)
+        self.n_pairs = pb.n_pairs
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().bioalign_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(lib().bioalign_plan_workspace_bytes(self._h))
+
+    @property
+    def cells(self) -> int:
+        return int(lib().bioalign_plan_cells(self._h))
+
+    def run(self, d_s1, d_s1_off, d_s2, d_s2_off, d_scores, d_t1, d_t2, d_t_off, d_t_len, stream=0):
+        """All arguments are raw device addresses (ints), e.g. torch tensors' data_ptr()."""
+        rc = lib().bioalign_plan_run(self._h, d_s1, d_s1_off, d_s2, d_s2_off, d_scores,
+                                     d_t1, d_t2, d_t_off, d_t_len, stream)
+        if rc != 0:
+            self.engine._raise(rc)
+
+    def last_dp_ms(self):
+        ms, n = C.c_float(), C.c_int()
+        rc = lib().bioalign_plan_last_dp_ms(self._h, C.byref(ms), C.byref(n))
+        if rc != 0:
+            self.engine._raise(rc)
+        return ms.value, n.value

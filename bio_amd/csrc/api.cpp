@@ -1,0 +1,619 @@
+// api.cpp -- host side of the C ABI declared in include/bioalign.h:
+// contexts, planning (shape-sorting pairs into bundles, sizing the HBM
+// workspace), and the staged run (pack -> DP -> traceback) on HIP streams.
+//
+// No CPU alignment code lives here: when HIP is unusable every entry point
+// fails with BIOALIGN_ENODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/bioalign.h"
+#include "common.h"
+
+extern "C" size_t ba_dp_linear_lds_bytes(int nb, int nb4, int na_pad, int R, int waves);
+extern "C" hipError_t ba_launch_pack(const BaPackParams &P, hipStream_t st);
+extern "C" hipError_t ba_launch_dp_linear(const BaDpParams &P, int mode, int R, int waves, hipStream_t st);
+extern "C" hipError_t ba_launch_trace_linear(const BaTraceParams &P, int mode, int R, hipStream_t st);
+
+namespace {
+
+thread_local std::string g_create_error;
+
+std::string vfmt(const char *fmt, va_list ap)
+{
+    char buf[1024];
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    return std::string(buf);
+}
+
+}  // namespace
+
+struct bioalign_ctx {
+    std::vector<int> devices;
+    std::string err;
+    int code = 0;  // code of the last failure
+    int fail(int c, const char *fmt, ...)
+    {
+        va_list ap;
+        va_start(ap, fmt);
+        err = vfmt(fmt, ap);
+        va_end(ap);
+        code = c;
+        return c;
+    }
+};
+
+#define HIP_TRY(ctx, call)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return (ctx)->fail(BIOALIGN_EHIP, "%s failed: %s (%s:%d)", #call,                \
+                               hipGetErrorString(e_), __FILE__, __LINE__);                  \
+    } while (0)
+
+struct Chunk {
+    uint32_t bundle_begin, bundle_end;
+};
+
+struct bioalign_plan {
+    bioalign_ctx *ctx = nullptr;
+    int device = 0;
+    uint64_t n_pairs = 0;
+    int mode = 0;
+    bool affine = false;
+    bool score_only = false;
+    int gap = 0, gap_open = 0, gap_ext = 0;
+    uint8_t gap_symbol = '-';
+    int na = 0, nb = 0, nb4 = 0, na_pad = 0;
+    int R = 32, waves = 4;
+    int key_shift = 0;
+    uint64_t cells = 0;
+    std::vector<BaBundle> bundles;
+    std::vector<Chunk> chunks;
+    // device memory
+    BaBundle *d_bundles = nullptr;
+    uint32_t *d_perm = nullptr;
+    uint8_t *d_code1 = nullptr, *d_code2 = nullptr;
+    int32_t *d_table = nullptr;
+    uint32_t *d_wt = nullptr;
+    uint32_t *d_s1w = nullptr, *d_s2w = nullptr;
+    int32_t *d_hb = nullptr;
+    uint32_t *d_dir = nullptr;
+    BaLocalBest *d_best = nullptr;
+    uint64_t ws_bytes = 0;
+    std::vector<hipEvent_t> ev0, ev1;
+    bool ran = false;
+    std::vector<void *> allocs;
+};
+
+namespace {
+
+int dev_alloc(bioalign_plan *pl, void **p, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess)
+        return pl->ctx->fail(BIOALIGN_ENOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    pl->allocs.push_back(*p);
+    pl->ws_bytes += bytes;
+    return 0;
+}
+
+int bit_length(uint64_t v)
+{
+    int b = 0;
+    while (v) {
+        ++b;
+        v >>= 1;
+    }
+    return b;
+}
+
+uint64_t env_u64(const char *name, uint64_t dflt)
+{
+    const char *s = getenv(name);
+    if (!s || !*s) return dflt;
+    return strtoull(s, nullptr, 10);
+}
+
+}  // namespace
+
+extern "C" int bioalign_abi_version(void) { return BIOALIGN_ABI_VERSION; }
+
+extern "C" bioalign_ctx *bioalign_create(const int *device_ids, int n_devices)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = std::string("no usable HIP device: ") +
+                         (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                         " (this library has no CPU fallback)";
+        return nullptr;
+    }
+    bioalign_ctx *ctx = new bioalign_ctx;
+    if (!device_ids || n_devices <= 0) {
+        ctx->devices.push_back(0);
+    } else {
+        for (int i = 0; i < n_devices; ++i) {
+            if (device_ids[i] < 0 || device_ids[i] >= count) {
+                g_create_error = "device id out of range";
+                delete ctx;
+                return nullptr;
+            }
+            ctx->devices.push_back(device_ids[i]);
+        }
+    }
+    return ctx;
+}
+
+extern "C" void bioalign_destroy(bioalign_ctx *ctx) { delete ctx; }
+
+extern "C" const char *bioalign_last_error(const bioalign_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" int bioalign_device_count(const bioalign_ctx *ctx) { return ctx ? (int)ctx->devices.size() : 0; }
+
+extern "C" void bioalign_plan_destroy(bioalign_plan *pl)
+{
+    if (!pl) return;
+    (void)hipSetDevice(pl->ctx->devices[pl->device]);
+    for (void *p : pl->allocs) (void)hipFree(p);
+    for (hipEvent_t e : pl->ev0) (void)hipEventDestroy(e);
+    for (hipEvent_t e : pl->ev1) (void)hipEventDestroy(e);
+    delete pl;
+}
+
+extern "C" uint64_t bioalign_plan_workspace_bytes(const bioalign_plan *pl) { return pl ? pl->ws_bytes : 0; }
+extern "C" uint64_t bioalign_plan_cells(const bioalign_plan *pl) { return pl ? pl->cells : 0; }
+
+static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
+{
+    bioalign_ctx *ctx = pl->ctx;
+    if (in->mode < BIOALIGN_GLOBAL || in->mode > BIOALIGN_OVERLAP)
+        return ctx->fail(BIOALIGN_EINVAL, "unknown mode %d", in->mode);
+    if (!in->s1_off || !in->s2_off || !in->score_table || !in->code1 || !in->code2)
+        return ctx->fail(BIOALIGN_EINVAL, "null offsets / score table / code maps");
+    if (in->na <= 0 || in->nb <= 0 || in->na > 255 || in->nb > 255)
+        return ctx->fail(BIOALIGN_EINVAL, "alphabet sizes must be in 1..255 (got %d, %d)", in->na, in->nb);
+    const uint64_t N = in->n_pairs;
+    if (N > 0xfffffff0ull) return ctx->fail(BIOALIGN_EINVAL, "too many pairs");
+    pl->n_pairs = N;
+    pl->mode = in->mode;
+    pl->affine = in->gap_open != in->gap_extend;
+    pl->score_only = (in->flags & BIOALIGN_SCORE_ONLY) != 0;
+    pl->gap = pl->gap_open = in->gap_open;
+    pl->gap_ext = in->gap_extend;
+    pl->gap_symbol = in->gap_symbol;
+    pl->na = in->na;
+    pl->nb = in->nb;
+    if (pl->affine) return ctx->fail(BIOALIGN_EUNSUPPORTED, "affine gaps are not implemented yet");
+    if (pl->gap < 0)
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "negative gap penalty %d is outside the fast kernels", pl->gap);
+
+    // shapes
+    std::vector<uint32_t> len1(N), len2(N);
+    uint64_t max_n = 0, max_m = 0, min_nm_max = 0;
+    for (uint64_t p = 0; p < N; ++p) {
+        if (in->s1_off[p + 1] < in->s1_off[p] || in->s2_off[p + 1] < in->s2_off[p])
+            return ctx->fail(BIOALIGN_EINVAL, "offsets must be non-decreasing (pair %llu)", (unsigned long long)p);
+        const uint64_t a = in->s1_off[p + 1] - in->s1_off[p], b = in->s2_off[p + 1] - in->s2_off[p];
+        if (a > 0x7fffffu || b > 0x7fffffu)
+            return ctx->fail(BIOALIGN_EUNSUPPORTED, "pair %llu is longer than 8M symbols; use bioalign_long",
+                             (unsigned long long)p);
+        len1[p] = (uint32_t)a;
+        len2[p] = (uint32_t)b;
+        max_n = std::max(max_n, a);
+        max_m = std::max(max_m, b);
+        min_nm_max = std::max(min_nm_max, std::min(a, b));
+        pl->cells += a * b;
+    }
+    if (N && (in->s1_off[0] != 0 || in->s2_off[0] != 0))
+        return ctx->fail(BIOALIGN_EINVAL, "offsets must start at 0");
+
+    // int8 profile with the bias folded in (kernels.hip: biased score space)
+    const int bias = (pl->mode == BIOALIGN_LOCAL) ? 0 : 2 * pl->gap;
+    int wmax = 0;
+    for (int i = 0; i < pl->na * pl->nb; ++i) {
+        const int64_t v = (int64_t)in->score_table[i] + bias;
+        if (v < -127 || v > 127)
+            return ctx->fail(BIOALIGN_EUNSUPPORTED,
+                             "score %d with gap %d does not fit the int8 profile of the fast kernels",
+                             in->score_table[i], pl->gap);
+        wmax = std::max(wmax, in->score_table[i]);
+    }
+    pl->nb4 = (pl->nb + 3) / 4;
+    pl->na_pad = ((pl->na + 1 + 31) / 32) * 32;
+    pl->key_shift = std::max(1, bit_length(max_m));
+    if (pl->mode == BIOALIGN_LOCAL) {
+        const uint64_t hmax = min_nm_max * (uint64_t)std::max(wmax, 0);
+        if (bit_length(hmax) + pl->key_shift > 30)
+            return ctx->fail(BIOALIGN_EUNSUPPORTED, "local scores up to %llu do not fit the 32-bit running-best key",
+                             (unsigned long long)hmax);
+    }
+
+    // strip height and block shape: the strip profile (nb * R bytes per lane) lives in LDS
+    pl->R = (pl->nb <= 6) ? 32 : 16;
+    pl->waves = 4;
+    while (pl->waves > 1 && ba_dp_linear_lds_bytes(pl->nb, pl->nb4, pl->na_pad, pl->R, pl->waves) > 40 * 1024)
+        pl->waves >>= 1;
+    if (ba_dp_linear_lds_bytes(pl->nb, pl->nb4, pl->na_pad, pl->R, pl->waves) > 160 * 1024)
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "alphabet of %d column symbols needs more LDS than a CU has", pl->nb);
+    const int R = pl->R;
+    const int dirw = (R == 32) ? 2 : 1;
+
+    // shape-sort the pairs; identical shapes become bundles of <= 64
+    std::vector<uint32_t> perm(N);
+    std::iota(perm.begin(), perm.end(), 0u);
+    bool uniform = true;
+    for (uint64_t p = 1; p < N && uniform; ++p) uniform = len1[p] == len1[0] && len2[p] == len2[0];
+    if (!uniform)
+        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) {
+            return len1[a] != len1[b] ? len1[a] < len1[b] : len2[a] < len2[b];
+        });
+    uint64_t budget = env_u64("BIOALIGN_WORKSPACE_BYTES", 96ull << 30);
+    pl->bundles.clear();
+    pl->chunks.clear();
+    uint64_t o_s1w = 0, o_s2w = 0, o_hb = 0, o_dir = 0;
+    uint64_t m_s1w = 0, m_s2w = 0, m_hb = 0, m_dir = 0;
+    uint32_t chunk_begin = 0;
+    for (uint64_t q = 0; q < N;) {
+        const uint32_t n = len1[perm[q]], m = len2[perm[q]];
+        uint64_t e = q + 1;
+        while (e < N && e - q < BA_WAVE && len1[perm[e]] == n && len2[perm[e]] == m) ++e;
+        const uint64_t strips = (n + R - 1) / R;
+        const uint64_t sz_s1w = strips * R / 4 * 64, sz_s2w = (uint64_t)((m + 3) / 4) * 64;
+        const uint64_t sz_hb = (uint64_t)(m + 1) * 64, sz_dir = strips * m * 64 * dirw;
+        const uint64_t after = (o_s1w + sz_s1w + o_s2w + sz_s2w + o_hb + sz_hb + o_dir + sz_dir) * 4;
+        if (after > budget && pl->bundles.size() > chunk_begin) {
+            pl->chunks.push_back({chunk_begin, (uint32_t)pl->bundles.size()});
+            chunk_begin = (uint32_t)pl->bundles.size();
+            o_s1w = o_s2w = o_hb = o_dir = 0;
+        }
+        BaBundle B;
+        B.n = n;
+        B.m = m;
+        B.first = (uint32_t)q;
+        B.count = (uint32_t)(e - q);
+        B.s1w_off = o_s1w;
+        B.s2w_off = o_s2w;
+        B.hb_off = o_hb;
+        B.dir_off = o_dir;
+        pl->bundles.push_back(B);
+        o_s1w += sz_s1w;
+        o_s2w += sz_s2w;
+        o_hb += sz_hb;
+        o_dir += sz_dir;
+        m_s1w = std::max(m_s1w, o_s1w);
+        m_s2w = std::max(m_s2w, o_s2w);
+        m_hb = std::max(m_hb, o_hb);
+        m_dir = std::max(m_dir, o_dir);
+        q = e;
+    }
+    if (pl->bundles.size() > chunk_begin) pl->chunks.push_back({chunk_begin, (uint32_t)pl->bundles.size()});
+
+    // transposed int8 table: dword [c][a] = bytes score(a, 4c..4c+3) + bias; the padding
+    // row (code na) and unused columns hold -128
+    std::vector<uint32_t> wt((size_t)pl->nb4 * pl->na_pad, 0x80808080u);
+    for (int c = 0; c < pl->nb4; ++c)
+        for (int a = 0; a < pl->na; ++a) {
+            uint32_t w = 0;
+            for (int q = 0; q < 4; ++q) {
+                const int b = 4 * c + q;
+                const int v = b < pl->nb ? in->score_table[a * pl->nb + b] + bias : -128;
+                w |= (uint32_t)(uint8_t)(int8_t)v << (8 * q);
+            }
+            wt[(size_t)c * pl->na_pad + a] = w;
+        }
+
+    // device memory
+    HIP_TRY(ctx, hipSetDevice(ctx->devices[pl->device]));
+    int rc;
+    if ((rc = dev_alloc(pl, (void **)&pl->d_bundles, pl->bundles.size() * sizeof(BaBundle)))) return rc;
+    if ((rc = dev_alloc(pl, (void **)&pl->d_perm, N * 4))) return rc;
+    if ((rc = dev_alloc(pl, (void **)&pl->d_code1, 256))) return rc;
+    if ((rc = dev_alloc(pl, (void **)&pl->d_code2, 256))) return rc;
+    if ((rc = dev_alloc(pl, (void **)&pl->d_table, (size_t)pl->na * pl->nb * 4))) return rc;
+    if ((rc = dev_alloc(pl, (void **)&pl->d_wt, wt.size() * 4))) return rc;
+    if ((rc = dev_alloc(pl, (void **)&pl->d_s1w, m_s1w * 4))) return rc;
+    if ((rc = dev_alloc(pl, (void **)&pl->d_s2w, m_s2w * 4))) return rc;
+    if ((rc = dev_alloc(pl, (void **)&pl->d_hb, m_hb * 4))) return rc;
+    if ((rc = dev_alloc(pl, (void **)&pl->d_dir, m_dir * 4))) return rc;
+    if ((rc = dev_alloc(pl, (void **)&pl->d_best, (N ? N : 1) * sizeof(BaLocalBest)))) return rc;
+    if (!pl->bundles.empty())
+        HIP_TRY(ctx, hipMemcpy(pl->d_bundles, pl->bundles.data(), pl->bundles.size() * sizeof(BaBundle),
+                               hipMemcpyHostToDevice));
+    if (N) HIP_TRY(ctx, hipMemcpy(pl->d_perm, perm.data(), N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(pl->d_code1, in->code1, 256, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(pl->d_code2, in->code2, 256, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(pl->d_table, in->score_table, (size_t)pl->na * pl->nb * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(pl->d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+    pl->ev0.resize(pl->chunks.size());
+    pl->ev1.resize(pl->chunks.size());
+    for (size_t c = 0; c < pl->chunks.size(); ++c) {
+        HIP_TRY(ctx, hipEventCreate(&pl->ev0[c]));
+        HIP_TRY(ctx, hipEventCreate(&pl->ev1[c]));
+    }
+    return 0;
+}
+
+extern "C" bioalign_plan *bioalign_plan_create(bioalign_ctx *ctx, int device_index, const bioalign_batch_t *in)
+{
+    if (!ctx) return nullptr;
+    if (!in) {
+        ctx->fail(BIOALIGN_EINVAL, "null batch");
+        return nullptr;
+    }
+    if (device_index < 0 || device_index >= (int)ctx->devices.size()) {
+        ctx->fail(BIOALIGN_EINVAL, "device index %d out of range", device_index);
+        return nullptr;
+    }
+    bioalign_plan *pl = new bioalign_plan;
+    pl->ctx = ctx;
+    pl->device = device_index;
+    if (plan_build(pl, in) != 0) {
+        bioalign_plan_destroy(pl);
+        return nullptr;
+    }
+    return pl;
+}
+
+extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const uint64_t *d_s1_off,
+                                 const uint8_t *d_s2, const uint64_t *d_s2_off, int64_t *d_scores,
+                                 uint8_t *d_t1, uint8_t *d_t2, uint64_t *d_t_off, uint64_t *d_t_len,
+                                 void *stream)
+{
+    if (!pl) return BIOALIGN_EINVAL;
+    bioalign_ctx *ctx = pl->ctx;
+    if (pl->n_pairs == 0) return 0;
+    if (!d_s1_off || !d_s2_off || !d_scores)
+        return ctx->fail(BIOALIGN_EINVAL, "null device pointer");
+    if (!pl->score_only && (!d_t1 || !d_t2 || !d_t_off || !d_t_len))
+        return ctx->fail(BIOALIGN_EINVAL, "trace buffers are required unless BIOALIGN_SCORE_ONLY is set");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->devices[pl->device]));
+    for (size_t c = 0; c < pl->chunks.size(); ++c) {
+        const Chunk ch = pl->chunks[c];
+        BaPackParams pk;
+        pk.bundles = pl->d_bundles;
+        pk.bundle_begin = ch.bundle_begin;
+        pk.bundle_end = ch.bundle_end;
+        pk.perm = pl->d_perm;
+        pk.s1 = d_s1;
+        pk.s2 = d_s2;
+        pk.s1_off = d_s1_off;
+        pk.s2_off = d_s2_off;
+        pk.code1 = pl->d_code1;
+        pk.code2 = pl->d_code2;
+        pk.s1w = pl->d_s1w;
+        pk.s2w = pl->d_s2w;
+        pk.pad_code = (uint32_t)pl->na;
+        pk.rows_per_strip = pl->R;
+        HIP_TRY(ctx, ba_launch_pack(pk, st));
+
+        BaDpParams dp;
+        dp.bundles = pl->d_bundles;
+        dp.bundle_begin = ch.bundle_begin;
+        dp.bundle_end = ch.bundle_end;
+        dp.s1w = pl->d_s1w;
+        dp.s2w = pl->d_s2w;
+        dp.hb = pl->d_hb;
+        dp.dir = pl->d_dir;
+        dp.best = pl->d_best;
+        dp.wt = pl->d_wt;
+        dp.nb = pl->nb;
+        dp.nb4 = pl->nb4;
+        dp.na_pad = pl->na_pad;
+        dp.gap = pl->gap;
+        dp.gap_open = pl->gap_open;
+        dp.gap_ext = pl->gap_ext;
+        dp.key_shift = pl->key_shift;
+        HIP_TRY(ctx, hipEventRecord(pl->ev0[c], st));
+        HIP_TRY(ctx, ba_launch_dp_linear(dp, pl->mode, pl->R, pl->waves, st));
+        HIP_TRY(ctx, hipEventRecord(pl->ev1[c], st));
+
+        BaTraceParams tr;
+        tr.bundles = pl->d_bundles;
+        tr.bundle_begin = ch.bundle_begin;
+        tr.bundle_end = ch.bundle_end;
+        tr.perm = pl->d_perm;
+        tr.s1 = d_s1;
+        tr.s2 = d_s2;
+        tr.s1_off = d_s1_off;
+        tr.s2_off = d_s2_off;
+        tr.code1 = pl->d_code1;
+        tr.code2 = pl->d_code2;
+        tr.table = pl->d_table;
+        tr.nb = pl->nb;
+        tr.hb = pl->d_hb;
+        tr.dir = pl->d_dir;
+        tr.best = pl->d_best;
+        tr.gap = pl->gap;
+        tr.gap_open = pl->gap_open;
+        tr.gap_ext = pl->gap_ext;
+        tr.rows_per_strip = pl->R;
+        tr.score_only = pl->score_only ? 1 : 0;
+        tr.gap_symbol = pl->gap_symbol;
+        tr.scores = d_scores;
+        tr.t1 = d_t1;
+        tr.t2 = d_t2;
+        tr.t_off = d_t_off;
+        tr.t_len = d_t_len;
+        HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, st));
+    }
+    pl->ran = true;
+    return 0;
+}
+
+extern "C" int bioalign_plan_last_dp_ms(bioalign_plan *pl, float *ms, int *n_launches)
+{
+    if (!pl || !ms) return BIOALIGN_EINVAL;
+    bioalign_ctx *ctx = pl->ctx;
+    *ms = 0.f;
+    if (n_launches) *n_launches = 0;
+    if (!pl->ran) return ctx->fail(BIOALIGN_EINVAL, "plan has not run yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->devices[pl->device]));
+    for (size_t c = 0; c < pl->chunks.size(); ++c) {
+        float t = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&t, pl->ev0[c], pl->ev1[c]));
+        *ms += t;
+    }
+    if (n_launches) *n_launches = (int)pl->chunks.size();
+    return 0;
+}
+
+// One device's share of bioalign_batch: pairs [lo, hi) of the caller's batch.
+static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in, bioalign_result_t *out,
+                     uint64_t lo, uint64_t hi, std::string *err)
+{
+    // a private context object so that concurrent shares do not race on the error string
+    bioalign_ctx local;
+    local.devices = ctx->devices;
+    auto fail = [&](int rc) {
+        *err = local.err;
+        return rc;
+    };
+    const uint64_t N = hi - lo;
+    if (N == 0) return 0;
+    // rebase the offsets of the share to 0
+    std::vector<uint64_t> o1(N + 1), o2(N + 1);
+    const uint64_t b1 = in->s1_off[lo], b2 = in->s2_off[lo];
+    for (uint64_t p = 0; p <= N; ++p) {
+        o1[p] = in->s1_off[lo + p] - b1;
+        o2[p] = in->s2_off[lo + p] - b2;
+    }
+    bioalign_batch_t sub = *in;
+    sub.s1 = in->s1 ? in->s1 + b1 : nullptr;
+    sub.s2 = in->s2 ? in->s2 + b2 : nullptr;
+    sub.s1_off = o1.data();
+    sub.s2_off = o2.data();
+    sub.n_pairs = N;
+    bioalign_plan *pl = bioalign_plan_create(&local, dev_index, &sub);
+    if (!pl) return fail(local.code ? local.code : BIOALIGN_EINVAL);
+    const bool traces = !pl->score_only;
+    const uint64_t bytes1 = o1[N], bytes2 = o2[N], cap = bytes1 + bytes2;
+    uint8_t *d_s1 = nullptr, *d_s2 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;
+    uint64_t *d_o1 = nullptr, *d_o2 = nullptr, *d_toff = nullptr, *d_tlen = nullptr;
+    int64_t *d_sc = nullptr;
+    int rc = 0;
+    hipStream_t st = nullptr;
+    std::vector<uint64_t> toff, tlen;
+#define SHARE_TRY(call)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            rc = local.fail(BIOALIGN_EHIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
+            goto done;                                                                       \
+        }                                                                                    \
+    } while (0)
+    SHARE_TRY(hipSetDevice(ctx->devices[dev_index]));
+    SHARE_TRY(hipStreamCreate(&st));
+    SHARE_TRY(hipMalloc((void **)&d_s1, bytes1 + 16));
+    SHARE_TRY(hipMalloc((void **)&d_s2, bytes2 + 16));
+    SHARE_TRY(hipMalloc((void **)&d_o1, (N + 1) * 8));
+    SHARE_TRY(hipMalloc((void **)&d_o2, (N + 1) * 8));
+    SHARE_TRY(hipMalloc((void **)&d_sc, N * 8));
+    if (traces) {
+        SHARE_TRY(hipMalloc((void **)&d_t1, cap + 16));
+        SHARE_TRY(hipMalloc((void **)&d_t2, cap + 16));
+        SHARE_TRY(hipMalloc((void **)&d_toff, N * 8));
+        SHARE_TRY(hipMalloc((void **)&d_tlen, N * 8));
+    }
+    if (bytes1) SHARE_TRY(hipMemcpyAsync(d_s1, sub.s1, bytes1, hipMemcpyHostToDevice, st));
+    if (bytes2) SHARE_TRY(hipMemcpyAsync(d_s2, sub.s2, bytes2, hipMemcpyHostToDevice, st));
+    SHARE_TRY(hipMemcpyAsync(d_o1, o1.data(), (N + 1) * 8, hipMemcpyHostToDevice, st));
+    SHARE_TRY(hipMemcpyAsync(d_o2, o2.data(), (N + 1) * 8, hipMemcpyHostToDevice, st));
+    rc = bioalign_plan_run(pl, d_s1, d_o1, d_s2, d_o2, d_sc, d_t1, d_t2, d_toff, d_tlen, st);
+    if (rc) goto done;
+    SHARE_TRY(hipMemcpyAsync(out->scores + lo, d_sc, N * 8, hipMemcpyDeviceToHost, st));
+    if (traces) {
+        // the share's slots start at byte b1+b2 of the caller's trace buffers
+        if (cap) {
+            SHARE_TRY(hipMemcpyAsync(out->t1 + b1 + b2, d_t1, cap, hipMemcpyDeviceToHost, st));
+            SHARE_TRY(hipMemcpyAsync(out->t2 + b1 + b2, d_t2, cap, hipMemcpyDeviceToHost, st));
+        }
+        toff.resize(N);
+        tlen.resize(N);
+        SHARE_TRY(hipMemcpyAsync(toff.data(), d_toff, N * 8, hipMemcpyDeviceToHost, st));
+        SHARE_TRY(hipMemcpyAsync(tlen.data(), d_tlen, N * 8, hipMemcpyDeviceToHost, st));
+    }
+    SHARE_TRY(hipStreamSynchronize(st));
+    if (traces)
+        for (uint64_t p = 0; p < N; ++p) {
+            out->t_off[lo + p] = toff[p] + b1 + b2;
+            out->t_len[lo + p] = tlen[p];
+        }
+done:
+    (void)hipFree(d_s1);
+    (void)hipFree(d_s2);
+    (void)hipFree(d_o1);
+    (void)hipFree(d_o2);
+    (void)hipFree(d_sc);
+    (void)hipFree(d_t1);
+    (void)hipFree(d_t2);
+    (void)hipFree(d_toff);
+    (void)hipFree(d_tlen);
+    if (st) (void)hipStreamDestroy(st);
+    // bioalign_plan_destroy touches pl->ctx (== &local), still alive here
+    bioalign_plan_destroy(pl);
+    if (rc) *err = local.err;
+    return rc;
+#undef SHARE_TRY
+}
+
+extern "C" int bioalign_batch(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *out)
+{
+    if (!ctx) return BIOALIGN_EINVAL;
+    if (!in || !out) return ctx->fail(BIOALIGN_EINVAL, "null argument");
+    if (!in->s1_off || !in->s2_off) return ctx->fail(BIOALIGN_EINVAL, "null offsets");
+    const uint64_t N = in->n_pairs;
+    if (N == 0) return 0;
+    if (!out->scores) return ctx->fail(BIOALIGN_EINVAL, "null scores buffer");
+    const bool traces = !(in->flags & BIOALIGN_SCORE_ONLY);
+    if (traces && (!out->t1 || !out->t2 || !out->t_off || !out->t_len))
+        return ctx->fail(BIOALIGN_EINVAL, "trace buffers are required unless BIOALIGN_SCORE_ONLY is set");
+    if ((in->s1_off[N] && !in->s1) || (in->s2_off[N] && !in->s2))
+        return ctx->fail(BIOALIGN_EINVAL, "null sequence bytes");
+    // split the pairs into contiguous ranges balanced by cell count, one per device
+    const int D = (int)ctx->devices.size();
+    std::vector<uint64_t> cut(D + 1, N);
+    cut[0] = 0;
+    if (D > 1) {
+        std::vector<double> pre(N + 1, 0.0);
+        for (uint64_t p = 0; p < N; ++p)
+            pre[p + 1] = pre[p] + (double)(in->s1_off[p + 1] - in->s1_off[p] + 1) *
+                                      (double)(in->s2_off[p + 1] - in->s2_off[p] + 1);
+        for (int d = 1; d < D; ++d) {
+            const double target = pre[N] * d / D;
+            cut[d] = (uint64_t)(std::lower_bound(pre.begin(), pre.end(), target) - pre.begin());
+            if (cut[d] < cut[d - 1]) cut[d] = cut[d - 1];
+            if (cut[d] > N) cut[d] = N;
+        }
+    }
+    std::vector<int> rcs(D, 0);
+    std::vector<std::string> errs(D);
+    if (D == 1) {
+        rcs[0] = run_share(ctx, 0, in, out, 0, N, &errs[0]);
+    } else {
+        std::vector<std::thread> th;
+        for (int d = 0; d < D; ++d)
+            th.emplace_back([&, d] { rcs[d] = run_share(ctx, d, in, out, cut[d], cut[d + 1], &errs[d]); });
+        for (auto &t : th) t.join();
+    }
+    for (int d = 0; d < D; ++d)
+        if (rcs[d]) {
+            ctx->err = errs[d];
+            return rcs[d];
+        }
+    return 0;
+}

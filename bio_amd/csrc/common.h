@@ -1,0 +1,84 @@
+// common.h -- structures shared by the host planner and the gfx950 kernels.
+//
+// Vocabulary (follows the reference's domain):
+//   pair    : one (s1, s2) alignment problem; s1 labels the rows (index i),
+//             s2 the columns (index j), as in align_affine.go:8-9.
+//   bundle  : up to 64 pairs of identical shape (len(s1), len(s2)); one
+//             wavefront aligns one bundle, one pair per lane.
+//   strip   : R consecutive rows of the DP matrix held in VGPRs while the
+//             wavefront sweeps the columns.
+//   boundary row : the last row of the previous strip (m+1 scores per lane),
+//             kept in HBM/L2, lane-interleaved so every access is one
+//             coalesced 256-byte line per wavefront.
+//   direction words : the bit-packed traceback matrix, one word per
+//             (strip, column, lane) and bit plane.
+#pragma once
+#include <stdint.h>
+
+#define BA_WAVE 64
+
+enum { BA_GLOBAL = 0, BA_LOCAL = 1, BA_FITTING = 2, BA_OVERLAP = 3 };
+
+struct BaBundle {
+    uint32_t n, m;     // len(s1), len(s2) of every pair in the bundle
+    uint32_t first;    // first position in the shape-sorted pair order
+    uint32_t count;    // pairs in the bundle (1..64)
+    uint64_t s1w_off;  // dword offset of the bundle's packed s1 code words
+    uint64_t s2w_off;  // dword offset of the bundle's packed s2 code words
+    uint64_t hb_off;   // int32 offset of the bundle's boundary row
+    uint64_t dir_off;  // dword offset of the bundle's direction words
+};
+
+// end cell of a local alignment, found by the DP kernel
+struct BaLocalBest {
+    int32_t score;
+    int32_t i, j;
+    int32_t pad;
+};
+
+struct BaPackParams {
+    const BaBundle *bundles;
+    uint32_t bundle_begin, bundle_end;
+    const uint32_t *perm;      // shape-sorted order -> caller's pair index
+    const uint8_t *s1, *s2;    // caller's concatenated bytes (device)
+    const uint64_t *s1_off, *s2_off;
+    const uint8_t *code1, *code2;  // [256] byte -> dense code
+    uint32_t *s1w, *s2w;
+    uint32_t pad_code;         // s1-side code of the padding rows
+    int rows_per_strip;
+};
+
+struct BaDpParams {
+    const BaBundle *bundles;
+    uint32_t bundle_begin, bundle_end;
+    const uint32_t *s1w, *s2w;
+    int32_t *hb;
+    uint32_t *dir;
+    BaLocalBest *best;     // indexed by sorted position
+    const uint32_t *wt;    // transposed int8 score table, dwords [nb4][na_pad]
+    int nb, nb4, na_pad;
+    int gap;               // linear gap penalty (>= 0 on this path)
+    int gap_open, gap_ext; // affine
+    int key_shift;         // local mode: bits reserved for the column in the running-best key
+};
+
+struct BaTraceParams {
+    const BaBundle *bundles;
+    uint32_t bundle_begin, bundle_end;
+    const uint32_t *perm;
+    const uint8_t *s1, *s2;
+    const uint64_t *s1_off, *s2_off;
+    const uint8_t *code1, *code2;
+    const int32_t *table;  // na * nb scores, as the caller gave them
+    int nb;
+    const int32_t *hb;
+    const uint32_t *dir;
+    const BaLocalBest *best;
+    int gap, gap_open, gap_ext;
+    int rows_per_strip;
+    int score_only;
+    uint8_t gap_symbol;
+    int64_t *scores;
+    uint8_t *t1, *t2;
+    uint64_t *t_off, *t_len;
+};

@@ -1,0 +1,165 @@
+/*
+ * bioalign.h -- C ABI of the MI355X (gfx950) batched pairwise-alignment engine.
+ *
+ * This is the drop-in boundary for soniakeys/bio's DP alignment path.  The
+ * reference has no FFI layer: its boundary is a handful of
+ * exported Go functions, so each entry point below names the Go function(s) a
+ * cgo wrapper would route through it.  All citations are file:line relative to
+ * the reference tree.  INTEGRATION.md shows the cgo binding.
+ *
+ * Conventions
+ *  - plain C types only; the library never keeps a caller pointer after a call
+ *    returns (cgo rule) except inside an explicit bioalign_plan, which only
+ *    keeps copies;
+ *  - return 0 on success, a negative BIOALIGN_E* code on failure, message via
+ *    bioalign_last_error();
+ *  - a context is used from one host thread at a time; separate contexts may
+ *    be used concurrently;
+ *  - the library fails loudly (BIOALIGN_ENODEVICE) when no GPU is usable:
+ *    there is no CPU fallback.
+ */
+#ifndef BIOALIGN_H
+#define BIOALIGN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BIOALIGN_ABI_VERSION 1
+
+/* Alignment modes = the `mode` strings of AlignPair (align_pair.go:5-16). */
+enum {
+    BIOALIGN_GLOBAL = 0,  /* AlignGlobal (align.go:76), AlignPair "global", AlignGlobalLS (align_linear.go:9), AlignGlobalAffine (align_affine.go:12) */
+    BIOALIGN_LOCAL = 1,   /* AlignLocal (align.go:152), AlignPair "local" */
+    BIOALIGN_FITTING = 2, /* AlignPair "fitting" (align_pair.go:157-166) */
+    BIOALIGN_OVERLAP = 3  /* AlignPair "overlap" (align_pair.go:186-195) */
+};
+
+/* flags */
+enum {
+    BIOALIGN_SCORE_ONLY = 1u << 0 /* skip the direction matrix and the traceback */
+};
+
+/* error codes */
+enum {
+    BIOALIGN_OK = 0,
+    BIOALIGN_EINVAL = -1,      /* bad argument (mode, sizes, null pointer) */
+    BIOALIGN_ENODEVICE = -2,   /* no usable HIP device / HIP runtime failure at start-up */
+    BIOALIGN_ENOMEM = -3,      /* host or device allocation failed */
+    BIOALIGN_EHIP = -4,        /* a HIP call failed; see bioalign_last_error */
+    BIOALIGN_EUNSUPPORTED = -5 /* parameters outside what the kernels cover (message says which) */
+};
+
+typedef struct bioalign_ctx bioalign_ctx;
+typedef struct bioalign_plan bioalign_plan;
+
+/*
+ * A batch of independent pairs.  Pair p is s1[s1_off[p], s1_off[p+1]) against
+ * s2[s2_off[p], s2_off[p+1]); offsets start at 0 and have n_pairs+1 entries.
+ *
+ * Scoring replaces the Aligner interface (align.go:5-8) with a table the
+ * wrapper materialises once per batch: code1/code2 map every
+ * byte of the s1 / s2 side to a dense code (< na / < nb) and
+ * score_table[code1[x]*nb + code2[y]] == Aligner.Score(x, y).  Bytes that do not
+ * occur in the batch may map to anything.
+ *
+ * gap_open == gap_extend selects the linear-gap recurrences of align.go /
+ * align_pair.go (indelPenalty = that value); otherwise the three-level Gotoh
+ * recurrences of align_affine.go:44-103 in integers, where a gap of length L
+ * costs gap_open + (L-1)*gap_extend.
+ */
+typedef struct {
+    const uint8_t *s1;
+    const uint64_t *s1_off;
+    const uint8_t *s2;
+    const uint64_t *s2_off;
+    uint64_t n_pairs;
+    int32_t mode;
+    const int32_t *score_table; /* na * nb, row-major */
+    int32_t na, nb;
+    const uint8_t *code1; /* [256] */
+    const uint8_t *code2; /* [256] */
+    int32_t gap_open;
+    int32_t gap_extend;
+    uint8_t gap_symbol; /* the package variable GapSymbol (align.go:3) */
+    uint32_t flags;
+} bioalign_batch_t;
+
+/*
+ * Results, in caller-allocated buffers.  scores has n_pairs entries (Go int).
+ * t1 and t2 each have capacity s1_off[n_pairs] + s2_off[n_pairs] bytes: pair p
+ * owns the slot [s1_off[p]+s2_off[p], s1_off[p+1]+s2_off[p+1]) -- the longest
+ * possible trace -- and its traces are the t_len[p] bytes starting at t_off[p]
+ * inside that slot (right aligned: the traceback writes them back to front, so
+ * no reversal pass is needed).  t_len[p] == 0 is the reference's nil trace.
+ * With BIOALIGN_SCORE_ONLY, t1/t2/t_off/t_len may be NULL.
+ */
+typedef struct {
+    int64_t *scores;
+    uint8_t *t1;
+    uint8_t *t2;
+    uint64_t *t_off;
+    uint64_t *t_len;
+} bioalign_result_t;
+
+/* Opens the engine on the given HIP devices (NULL / 0 = device 0 only). */
+bioalign_ctx *bioalign_create(const int *device_ids, int n_devices);
+void bioalign_destroy(bioalign_ctx *ctx);
+/* Message of the last failure on this context (or of a failed create when ctx is NULL). */
+const char *bioalign_last_error(const bioalign_ctx *ctx);
+int bioalign_abi_version(void);
+int bioalign_device_count(const bioalign_ctx *ctx);
+
+/*
+ * End to end on host buffers: plan, upload, run on the context's devices
+ * (pairs are split across them by cell count, no collective), download.
+ * Replaces the per-pair bodies of AlignGlobal / AlignLocal (align.go:76-249),
+ * AlignPair (align_pair.go:3-246), AlignGlobalLS (align_linear.go:9-45; here it
+ * returns what AlignGlobal returns, as its disabled test asks, align_test.go:55-66)
+ * and AlignGlobalAffine (align_affine.go:12-167; score as written, canonical
+ * traceback instead of the broken one).
+ */
+int bioalign_batch(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *out);
+
+/*
+ * The same work split into stages, for callers that keep data resident in HBM
+ * (pipelines, the benchmark).  A plan depends on the pair lengths, the mode and
+ * the scoring, not on the sequence bytes: it groups pairs into wavefront-sized
+ * bundles of equal shape, sizes and allocates the device workspace on device
+ * `device_index` of the context, and uploads the score tables.
+ * `in->s1` / `in->s2` may be NULL here.
+ */
+bioalign_plan *bioalign_plan_create(bioalign_ctx *ctx, int device_index, const bioalign_batch_t *in);
+void bioalign_plan_destroy(bioalign_plan *plan);
+/* Bytes of device memory the plan holds (workspace + tables). */
+uint64_t bioalign_plan_workspace_bytes(const bioalign_plan *plan);
+/* Interior cells (sum of len1*len2) the plan covers. */
+uint64_t bioalign_plan_cells(const bioalign_plan *plan);
+
+/*
+ * Runs the planned batch.  Every pointer is DEVICE memory on the plan's device:
+ * d_s1/d_s2 the concatenated bytes, d_s1_off/d_s2_off the uint64 offsets, and
+ * the outputs laid out as in bioalign_result_t.  Work is queued on `stream`
+ * (a hipStream_t, NULL = the default stream) and the call returns without
+ * waiting for it.  Packing, DP, and traceback kernels all run inside this call.
+ */
+int bioalign_plan_run(bioalign_plan *plan, const uint8_t *d_s1, const uint64_t *d_s1_off,
+                      const uint8_t *d_s2, const uint64_t *d_s2_off,
+                      int64_t *d_scores, uint8_t *d_t1, uint8_t *d_t2,
+                      uint64_t *d_t_off, uint64_t *d_t_len, void *stream);
+
+/*
+ * Timing hooks for the benchmark: the plan records HIP events around its DP
+ * kernel(s) on the launch stream.  After the stream has been synchronised this
+ * returns the duration of the DP kernel launches of the last bioalign_plan_run
+ * in milliseconds, and how many such launches there were.
+ */
+int bioalign_plan_last_dp_ms(bioalign_plan *plan, float *ms, int *n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
