@@ -31,7 +31,7 @@ EXPORTS = (
     "bioalign_plan_workspace_bytes",
     "bioalign_plan_cells",
     "bioalign_plan_run",
-    "bioalign_plan_last_dp_ms",
+    "bioalign_plan_dp_ms",
 )
 
 
@@ -103,8 +103,8 @@ def lib():
         L.bioalign_plan_cells.argtypes = [C.c_void_p]
         L.bioalign_plan_run.restype = C.c_int
         L.bioalign_plan_run.argtypes = [C.c_void_p] + [C.c_void_p] * 9 + [C.c_void_p]
-        L.bioalign_plan_last_dp_ms.restype = C.c_int
-        L.bioalign_plan_last_dp_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.bioalign_plan_dp_ms.restype = C.c_int
+        L.bioalign_plan_dp_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -249,9 +249,10 @@ class Plan:
         if rc != 0:
             self.engine._raise(rc)
 
-    def last_dp_ms(self):
+    def dp_ms(self):
+        """(summed ms, launches) of the DP kernel since the previous call; sync the stream first."""
         ms, n = C.c_float(), C.c_int()
-        rc = lib().bioalign_plan_last_dp_ms(self._h, C.byref(ms), C.byref(n))
+        rc = lib().bioalign_plan_dp_ms(self._h, C.byref(ms), C.byref(n))
         if rc != 0:
             self.engine._raise(rc)
         return ms.value, n.value

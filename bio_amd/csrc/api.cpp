@@ -90,7 +90,9 @@ struct bioalign_plan {
     uint32_t *d_dir = nullptr;
     BaLocalBest *d_best = nullptr;
     uint64_t ws_bytes = 0;
+    // timing hooks: a fixed pool of event pairs, one pair per DP launch since the last reset
     std::vector<hipEvent_t> ev0, ev1;
+    size_t ev_used = 0;
     bool ran = false;
     std::vector<void *> allocs;
 };
@@ -338,9 +340,10 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     HIP_TRY(ctx, hipMemcpy(pl->d_code2, in->code2, 256, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(pl->d_table, in->score_table, (size_t)pl->na * pl->nb * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(pl->d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
-    pl->ev0.resize(pl->chunks.size());
-    pl->ev1.resize(pl->chunks.size());
-    for (size_t c = 0; c < pl->chunks.size(); ++c) {
+    const size_t pool = 256;
+    pl->ev0.resize(pool);
+    pl->ev1.resize(pool);
+    for (size_t c = 0; c < pool; ++c) {
         HIP_TRY(ctx, hipEventCreate(&pl->ev0[c]));
         HIP_TRY(ctx, hipEventCreate(&pl->ev1[c]));
     }
@@ -418,9 +421,13 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         dp.gap_open = pl->gap_open;
         dp.gap_ext = pl->gap_ext;
         dp.key_shift = pl->key_shift;
-        HIP_TRY(ctx, hipEventRecord(pl->ev0[c], st));
+        const bool timed = pl->ev_used < pl->ev0.size();
+        if (timed) HIP_TRY(ctx, hipEventRecord(pl->ev0[pl->ev_used], st));
         HIP_TRY(ctx, ba_launch_dp_linear(dp, pl->mode, pl->R, pl->waves, st));
-        HIP_TRY(ctx, hipEventRecord(pl->ev1[c], st));
+        if (timed) {
+            HIP_TRY(ctx, hipEventRecord(pl->ev1[pl->ev_used], st));
+            ++pl->ev_used;
+        }
 
         BaTraceParams tr;
         tr.bundles = pl->d_bundles;
@@ -455,20 +462,20 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
     return 0;
 }
 
-extern "C" int bioalign_plan_last_dp_ms(bioalign_plan *pl, float *ms, int *n_launches)
+extern "C" int bioalign_plan_dp_ms(bioalign_plan *pl, float *ms, int *n_launches)
 {
     if (!pl || !ms) return BIOALIGN_EINVAL;
     bioalign_ctx *ctx = pl->ctx;
     *ms = 0.f;
     if (n_launches) *n_launches = 0;
-    if (!pl->ran) return ctx->fail(BIOALIGN_EINVAL, "plan has not run yet");
     HIP_TRY(ctx, hipSetDevice(ctx->devices[pl->device]));
-    for (size_t c = 0; c < pl->chunks.size(); ++c) {
+    for (size_t c = 0; c < pl->ev_used; ++c) {
         float t = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&t, pl->ev0[c], pl->ev1[c]));
         *ms += t;
     }
-    if (n_launches) *n_launches = (int)pl->chunks.size();
+    if (n_launches) *n_launches = (int)pl->ev_used;
+    pl->ev_used = 0;
     return 0;
 }
 

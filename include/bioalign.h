@@ -152,12 +152,14 @@ int bioalign_plan_run(bioalign_plan *plan, const uint8_t *d_s1, const uint64_t *
                       uint64_t *d_t_off, uint64_t *d_t_len, void *stream);
 
 /*
- * Timing hooks for the benchmark: the plan records HIP events around its DP
- * kernel(s) on the launch stream.  After the stream has been synchronised this
- * returns the duration of the DP kernel launches of the last bioalign_plan_run
- * in milliseconds, and how many such launches there were.
+ * Timing hooks for the benchmark (no counterpart in the reference): the plan
+ * records a pair of HIP events around every DP kernel launch, on the launch
+ * stream, into a fixed pool of 256 pairs.  Once the stream has been
+ * synchronised this returns the summed duration in milliseconds of the DP
+ * launches recorded since the previous call, and their number, and empties the
+ * pool.  Launches beyond the pool size are not timed.
  */
-int bioalign_plan_last_dp_ms(bioalign_plan *plan, float *ms, int *n_launches);
+int bioalign_plan_dp_ms(bioalign_plan *plan, float *ms, int *n_launches);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@
  */
 #include "bio_oracle.h"
 
+#include <malloc.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
@@ -928,6 +929,11 @@ int64_t bo_batch(int kind, int mode, const uint8_t *s1, const uint64_t *s1_off,
 {
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
+    /* keep the per-call matrices on the per-thread heaps: with glibc's default
+     * 128 KiB mmap threshold every call would mmap/munmap and the threads would
+     * serialise in the kernel (Go's allocator does not behave like that) */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
     pthread_t th[256];
     batch_job *jobs = (batch_job *)calloc(threads, sizeof(batch_job));
     if (!jobs) return BO_NOMEM;
