@@ -21,8 +21,8 @@
 
 extern "C" size_t ba_dp_linear_lds_bytes(int nb, int nb4, int na_pad, int R, int waves);
 extern "C" hipError_t ba_launch_pack(const BaPackParams &P, hipStream_t st);
-extern "C" hipError_t ba_launch_dp_linear(const BaDpParams &P, int mode, int R, int waves, hipStream_t st);
-extern "C" hipError_t ba_launch_trace_linear(const BaTraceParams &P, int mode, int R, hipStream_t st);
+extern "C" hipError_t ba_launch_dp_linear(const BaDpParams &P, int mode, int R, int K, int waves, hipStream_t st);
+extern "C" hipError_t ba_launch_trace_linear(const BaTraceParams &P, int mode, int R, int K, hipStream_t st);
 
 namespace {
 
@@ -75,7 +75,7 @@ struct bioalign_plan {
     uint8_t gap_symbol = '-';
     int na = 0, nb = 0, nb4 = 0, na_pad = 0;
     int R = 32, waves = 4;
-    int key_shift = 0;
+    int K = 2;  // residue bits per cell in the traceback matrix
     uint64_t cells = 0;
     std::vector<BaBundle> bundles;
     std::vector<Chunk> chunks;
@@ -236,23 +236,25 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     }
     pl->nb4 = (pl->nb + 3) / 4;
     pl->na_pad = ((pl->na + 1 + 31) / 32) * 32;
-    pl->key_shift = std::max(1, bit_length(max_m));
-    if (pl->mode == BIOALIGN_LOCAL) {
-        const uint64_t hmax = min_nm_max * (uint64_t)std::max(wmax, 0);
-        if (bit_length(hmax) + pl->key_shift > 30)
-            return ctx->fail(BIOALIGN_EUNSUPPORTED, "local scores up to %llu do not fit the 32-bit running-best key",
-                             (unsigned long long)hmax);
+    // residue bits: adjacent working-space scores differ by 0 .. max(w)+2g (kernels.hip)
+    {
+        const int64_t span = std::max<int64_t>((int64_t)wmax + 2 * (int64_t)pl->gap, 0) + 1;
+        pl->K = span <= 4 ? 2 : span <= 16 ? 4 : span <= 256 ? 8 : 0;
+        if (!pl->K)
+            return ctx->fail(BIOALIGN_EUNSUPPORTED, "score span %lld does not fit 8 residue bits", (long long)span);
     }
-
+    if ((max_n + max_m + 2) * 128 >= (1ull << 31))
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "pair too long for 32-bit scores on the batch path");
+    (void)min_nm_max;
     // strip height and block shape: the strip profile (nb * R bytes per lane) lives in LDS
-    pl->R = (pl->nb <= 6) ? 32 : 16;
+    pl->R = (pl->nb <= 6 && pl->K <= 4) ? 32 : 16;
     pl->waves = 4;
     while (pl->waves > 1 && ba_dp_linear_lds_bytes(pl->nb, pl->nb4, pl->na_pad, pl->R, pl->waves) > 40 * 1024)
         pl->waves >>= 1;
     if (ba_dp_linear_lds_bytes(pl->nb, pl->nb4, pl->na_pad, pl->R, pl->waves) > 160 * 1024)
         return ctx->fail(BIOALIGN_EUNSUPPORTED, "alphabet of %d column symbols needs more LDS than a CU has", pl->nb);
     const int R = pl->R;
-    const int dirw = (R == 32) ? 2 : 1;
+    const int chw = 4 * (R * pl->K / 32);  // residue dwords per lane per group of 4 columns
 
     // shape-sort the pairs; identical shapes become bundles of <= 64
     std::vector<uint32_t> perm(N);
@@ -275,7 +277,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         while (e < N && e - q < BA_WAVE && len1[perm[e]] == n && len2[perm[e]] == m) ++e;
         const uint64_t strips = (n + R - 1) / R;
         const uint64_t sz_s1w = strips * R / 4 * 64, sz_s2w = (uint64_t)((m + 3) / 4) * 64;
-        const uint64_t sz_hb = (uint64_t)(m + 1) * 64, sz_dir = strips * m * 64 * dirw;
+        const uint64_t sz_hb = (uint64_t)(m + 1) * 64, sz_dir = strips * (uint64_t)((m + 3) / 4) * 64 * chw;
         const uint64_t after = (o_s1w + sz_s1w + o_s2w + sz_s2w + o_hb + sz_hb + o_dir + sz_dir) * 4;
         if (after > budget && pl->bundles.size() > chunk_begin) {
             pl->chunks.push_back({chunk_begin, (uint32_t)pl->bundles.size()});
@@ -420,10 +422,9 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         dp.gap = pl->gap;
         dp.gap_open = pl->gap_open;
         dp.gap_ext = pl->gap_ext;
-        dp.key_shift = pl->key_shift;
         const bool timed = pl->ev_used < pl->ev0.size();
         if (timed) HIP_TRY(ctx, hipEventRecord(pl->ev0[pl->ev_used], st));
-        HIP_TRY(ctx, ba_launch_dp_linear(dp, pl->mode, pl->R, pl->waves, st));
+        HIP_TRY(ctx, ba_launch_dp_linear(dp, pl->mode, pl->R, pl->K, pl->waves, st));
         if (timed) {
             HIP_TRY(ctx, hipEventRecord(pl->ev1[pl->ev_used], st));
             ++pl->ev_used;
@@ -441,6 +442,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         tr.code1 = pl->d_code1;
         tr.code2 = pl->d_code2;
         tr.table = pl->d_table;
+        tr.na = pl->na;
         tr.nb = pl->nb;
         tr.hb = pl->d_hb;
         tr.dir = pl->d_dir;
@@ -449,6 +451,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         tr.gap_open = pl->gap_open;
         tr.gap_ext = pl->gap_ext;
         tr.rows_per_strip = pl->R;
+        tr.residue_bits = pl->K;
         tr.score_only = pl->score_only ? 1 : 0;
         tr.gap_symbol = pl->gap_symbol;
         tr.scores = d_scores;
@@ -456,7 +459,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         tr.t2 = d_t2;
         tr.t_off = d_t_off;
         tr.t_len = d_t_len;
-        HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, st));
+        HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, st));
     }
     pl->ran = true;
     return 0;

@@ -59,7 +59,6 @@ struct BaDpParams {
     int nb, nb4, na_pad;
     int gap;               // linear gap penalty (>= 0 on this path)
     int gap_open, gap_ext; // affine
-    int key_shift;         // local mode: bits reserved for the column in the running-best key
 };
 
 struct BaTraceParams {
@@ -70,12 +69,13 @@ struct BaTraceParams {
     const uint64_t *s1_off, *s2_off;
     const uint8_t *code1, *code2;
     const int32_t *table;  // na * nb scores, as the caller gave them
-    int nb;
+    int na, nb;
     const int32_t *hb;
     const uint32_t *dir;
     const BaLocalBest *best;
     int gap, gap_open, gap_ext;
     int rows_per_strip;
+    int residue_bits;
     int score_only;
     uint8_t gap_symbol;
     int64_t *scores;
