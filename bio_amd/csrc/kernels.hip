@@ -130,9 +130,12 @@ __device__ __forceinline__ void ba_linear_column(int (&h)[R], int (&rmax)[R], ui
 }
 
 // Layout of the residue words of one bundle (dwords):
-//   [strip][column group cg = (j-1)/4][lane][column c = (j-1)%4][word w]      WPC = R*K/32 words per column
-// so a lane's 4 columns x WPC words are one contiguous 16*WPC-byte chunk and a
-// wavefront stores a column group as 64 such chunks back to back.
+//   [strip][column group cg = (j-1)/4][lane][row block w][column c = (j-1)%4]
+// A word holds F = 32/K consecutive rows of one column (a "row block"); a strip
+// has WPC = R/F row blocks.  A lane's WPC x 4 words of one column group are one
+// contiguous 16*WPC-byte chunk, a wavefront stores a column group as 64 such
+// chunks back to back, and the 4 columns of one row block are one aligned uint4
+// -- the unit the traceback fetches.
 template <int MODE, int R, int K>
 __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
 {
@@ -259,11 +262,7 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
             }
             uint4 *dst = reinterpret_cast<uint4 *>(dirs + (size_t)cg * (64 * CHW));
 #pragma unroll
-            for (int q = 0; q < CHW / 4; ++q) {
-                const int e = q * 4;
-                dst[q] = make_uint4(acc[e / WPC][e % WPC], acc[(e + 1) / WPC][(e + 1) % WPC],
-                                    acc[(e + 2) / WPC][(e + 2) % WPC], acc[(e + 3) / WPC][(e + 3) % WPC]);
-            }
+            for (int w = 0; w < WPC; ++w) dst[w] = make_uint4(acc[0][w], acc[1][w], acc[2][w], acc[3][w]);
         };
         const int full_groups = m / 4;
         for (int cg = 0; cg < full_groups; ++cg) column_group(cg, std::true_type{});
@@ -297,116 +296,110 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
 // (align.go:126-143, 224-248; align_pair.go:197-216).
 // ----------------------------------------------------------------------------
 //
-// Residue chunks are staged through a per-lane 2x2 window in LDS (strip parity
-// x column-group parity), because the four cells one step needs -- (i,j),
-// (i-1,j), (i,j-1), (i-1,j-1) -- can straddle a strip and a column-group
-// boundary at once.  LDS words are lane-interleaved ([word][lane]), so any
-// per-lane index is bank-conflict free.
-template <int R, int K>
-struct BaResidueWindow {
-    static constexpr int WPC = R * K / 32;
-    static constexpr int CHW = 4 * WPC;
-    static constexpr int F = 32 / K;
-    static constexpr int WORDS = 4 * CHW + 4;  // 4 chunk slots + 4 tags, per lane
-    uint32_t *lds;        // this wave's window, already offset by the lane
-    const uint32_t *dir;  // bundle's residue words, already offset by lane*CHW
-    int cgs, front;
+// The wavefront walks the matrix ROW-SYNCHRONOUSLY: all lanes are in the same
+// row i (bundles are equal-shape, so a row is the same strip / row block / bit
+// position in every lane and those indices live in SGPRs); each lane takes its
+// left moves inside the row, then its up or diagonal move into row i-1.  Per
+// row block (F rows) a lane stages a band of BG column groups of residue words
+// around its current column in LDS: the band of the current row block and,
+// while the row is the first of its block, the band of the block above.  LDS
+// words are lane-interleaved ([word][lane]): any per-lane index is conflict free.
 
-    __device__ __forceinline__ void init()
-    {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) lds[(4 * CHW + t) * 64] = 0xffffffffu;
-    }
-    // K low bits of the working score of cell (i, j), i >= 1, j >= 1
-    __device__ __forceinline__ uint32_t get(int i, int j)
-    {
-        const int t = i - 1 + front;
-        const int s = t / R, r = t % R;
-        const int cg = (j - 1) >> 2, c = (j - 1) & 3;
-        const int slot = ((s & 1) << 1) | (cg & 1);
-        const uint32_t tag = (uint32_t)(s * cgs + cg);
-        if (lds[(4 * CHW + slot) * 64] != tag) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(dir + ((size_t)s * cgs + cg) * (64 * CHW));
-#pragma unroll
-            for (int q = 0; q < CHW / 4; ++q) {
-                const uint4 v = src[q];
-                lds[(slot * CHW + q * 4 + 0) * 64] = v.x;
-                lds[(slot * CHW + q * 4 + 1) * 64] = v.y;
-                lds[(slot * CHW + q * 4 + 2) * 64] = v.z;
-                lds[(slot * CHW + q * 4 + 3) * 64] = v.w;
-            }
-            lds[(4 * CHW + slot) * 64] = tag;
-        }
-        const uint32_t word = lds[(slot * CHW + c * WPC + r / F) * 64];
-        return (word >> (K * (r % F))) & ((1u << K) - 1u);
-    }
-};
-
-// byte `idx` of a byte array through a one-dword register cache (aligned loads)
+// byte `idx` of a byte array through a one-dword register cache.  Loads are
+// aligned dwords (an aligned dword that contains a valid byte never leaves that
+// byte's page) addressed from the kernel-argument pointer, so they stay
+// global_load (not flat_load) instructions.
 struct BaByteCache {
-    const uint8_t *base;
-    uint64_t tag;
+    const uint8_t *abase;  // array base rounded down to 4 bytes
+    int mis;               // array base - abase
+    int tag;               // dword index (from abase) held in `word`
     uint32_t word;
     __device__ __forceinline__ void init(const uint8_t *p)
     {
-        base = p;
-        tag = ~0ull;
+        mis = (int)((uint64_t)p & 3);
+        abase = p - mis;
+        tag = -1;
         word = 0;
     }
     __device__ __forceinline__ uint32_t get(int idx)
     {
-        const uint64_t a = (uint64_t)(base + idx);
-        const uint64_t al = a & ~3ull;
-        if (al != tag) {
-            word = *reinterpret_cast<const uint32_t *>(al);
-            tag = al;
+        const int pos = idx + mis;
+        const int dw = pos >> 2;
+        if (dw != tag) {
+            word = *reinterpret_cast<const uint32_t *>(abase + (size_t)dw * 4);
+            tag = dw;
+            // consume the value inside the branch, so that the wait for it stays in
+            // here and no s_waitcnt is executed on the (usual) hit path
+            asm volatile("" : "+v"(word));
         }
-        return (word >> ((a & 3) * 8)) & 0xffu;
+        return (word >> ((pos & 3) * 8)) & 0xffu;
     }
 };
 
 // Writes bytes back to front.  Bytes are collected per aligned dword and go out
-// as one dword store, except in the two dwords that can be shared with a
-// neighbouring slot (the one holding the slot's end and the one holding the
-// trace's first byte): those are written byte by byte.
+// as one dword store.  The two dwords that can be shared with a neighbouring
+// slot -- the one holding the slot's end and the one holding the trace's first
+// byte -- are written byte by byte at the end (finish()).
 struct BaBackWriter {
-    uint64_t end;    // absolute address one past the slot
-    uint64_t a;      // absolute address of the last byte written (== end when empty)
-    uint32_t word;   // bytes collected for the aligned dword that contains a
+    uint8_t *abase;    // buffer base rounded down to 4 bytes
+    int64_t end;       // offset (from abase) one past the slot
+    int64_t a;         // offset of the last byte written (== end when empty)
+    uint32_t word;     // bytes collected for the aligned dword that contains a
+    uint32_t topword;  // the collected dword that holds the slot's end, if it is partial
     __device__ __forceinline__ void init(uint8_t *buf, uint64_t end_index)
     {
-        end = (uint64_t)(buf + end_index);
+        const int mis = (int)((uint64_t)buf & 3);
+        abase = buf - mis;
+        end = (int64_t)end_index + mis;
         a = end;
         word = 0;
+        topword = 0;
     }
     __device__ __forceinline__ void put(uint32_t byte)
     {
         --a;
         word |= byte << ((uint32_t)(a & 3) * 8);
         if ((a & 3) == 0) {
-            if (a + 4 <= end) {
-                *reinterpret_cast<uint32_t *>(a) = word;
-            } else {  // the dword that holds the slot's end
-                for (uint64_t q = a; q < end; ++q) *reinterpret_cast<uint8_t *>(q) = (uint8_t)(word >> ((q & 3) * 8));
-            }
+            if (a + 4 <= end)
+                *reinterpret_cast<uint32_t *>(abase + a) = word;
+            else
+                topword = word;
             word = 0;
         }
     }
-    __device__ __forceinline__ void flush()
+    __device__ __forceinline__ int64_t length() const { return end - a; }
+    __device__ __forceinline__ void finish()
     {
-        if (a & 3) {
-            const uint64_t al = a & ~3ull;
-            for (uint64_t q = a; q < al + 4 && q < end; ++q)
-                *reinterpret_cast<uint8_t *>(q) = (uint8_t)(word >> ((q & 3) * 8));
+        const int64_t top_al = end & ~(int64_t)3;  // start of the dword that holds the slot's end
+        if (a & 3) {                               // partial dword at the front of the trace
+            const int64_t al = a & ~(int64_t)3;
+            if (al == top_al) topword = word;  // the trace never left the end dword
+            else
+                for (int64_t q = a; q < al + 4; ++q) abase[q] = (uint8_t)(word >> ((uint32_t)(q & 3) * 8));
+        }
+        if (end & 3) {
+            const int64_t lo = a > top_al ? a : top_al;
+            for (int64_t q = lo; q < end; ++q) abase[q] = (uint8_t)(topword >> ((uint32_t)(q & 3) * 8));
         }
     }
+};
+
+template <int R, int K>
+struct BaTraceGeom {
+    static constexpr int F = 32 / K;           // rows per residue word
+    static constexpr int WPC = R / F;          // row blocks per strip
+    static constexpr int CHW = 4 * WPC;        // dwords per lane per column group
+    static constexpr int BG = F / 4 + 2;       // column groups per staged band
+    static constexpr int BW = BG * 4;          // band width in columns
+    static constexpr int WORDS = 2 * BW;       // LDS words per lane (two bands)
 };
 
 template <int MODE, int R, int K>
 __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
 {
     extern __shared__ __align__(16) uint32_t lds[];
-    using Win = BaResidueWindow<R, K>;
+    using G = BaTraceGeom<R, K>;
+    constexpr int F = G::F, WPC = G::WPC, CHW = G::CHW, BG = G::BG, BW = G::BW;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
@@ -424,72 +417,77 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     const uint32_t b_idx = P.bundle_begin + blockIdx.x * waves + wave;
     if (b_idx >= P.bundle_end) return;
     const BaBundle B = P.bundles[b_idx];
-    if (lane >= (int)B.count) return;
-    const uint32_t p = P.perm[B.first + lane];
+    const bool live = lane < (int)B.count;
+    const uint32_t p = live ? P.perm[B.first + lane] : 0u;
     const int n = (int)B.n, m = (int)B.m;
     const int g = P.gap;
     const int32_t *hb = P.hb + B.hb_off + lane;
-    const uint64_t o1 = P.s1_off[p], o2 = P.s2_off[p];
-
-    Win win;
-    win.lds = lds + tbl_words + 128 + (size_t)wave * (Win::WORDS * 64) + lane;
-    win.dir = P.dir + B.dir_off + (size_t)lane * Win::CHW;
-    win.cgs = (m + 3) / 4;
-    win.front = ((n + R - 1) / R) * R - n;
-    win.init();
+    const uint32_t *dir = P.dir + B.dir_off + (size_t)lane * CHW;
+    const uint64_t o1 = live ? P.s1_off[p] : 0, o2 = live ? P.s2_off[p] : 0;
+    const int cgs = (m + 3) / 4;
+    const int front = ((n + R - 1) / R) * R - n;
+    uint32_t *band = lds + tbl_words + 128 + (size_t)wave * (G::WORDS * 64) + lane;  // band[word * 64]
 
     constexpr bool top_free = (MODE == BA_LOCAL || MODE == BA_FITTING);
     constexpr bool left_free = (MODE == BA_LOCAL || MODE == BA_OVERLAP);
     constexpr uint32_t MASK = (1u << K) - 1u;
-    const int off = (MODE == BA_LOCAL) ? g : 0;  // lower bound of an adjacent step is -off
+    const int off = (MODE == BA_LOCAL) ? g : 0;  // an adjacent step is never below -off
+    // exact neighbour score from the current exact score and the neighbour's residue
+    auto neighbour = [&](int c, uint32_t rho) { return c - ((int)(((uint32_t)c - rho + (uint32_t)off) & MASK) - off); };
+    // residue words (4 columns) of row block `rb` (counted over the front-padded rows), column group cg
+    auto block_words = [&](int rb, int cg) {
+        const int s = rb / WPC, w = rb % WPC;
+        return *reinterpret_cast<const uint4 *>(dir + ((size_t)s * cgs + cg) * (64 * CHW) + w * 4);
+    };
 
     // end cell, its working-space score `cur`, and the reported score
-    int i, j, cur;
-    int64_t score;
-    if (MODE == BA_GLOBAL) {
-        i = n;
-        j = m;
-        cur = hb[(size_t)m * 64];
-        score = (int64_t)cur - (int64_t)g * (n + m);
-    } else if (MODE == BA_LOCAL) {
-        const BaLocalBest bb = P.best[B.first + lane];
-        i = bb.i;
-        j = 0;
-        cur = 0;
-        score = bb.score;
-        if (bb.score > 0) {
-            // first column of row i that reaches the maximum: rebuild the row's exact
-            // scores left to right from their residues (H(i,0) = 0)
-            int v = 0;
+    int i = 0, j = 0, cur = 0;
+    int64_t score = 0;
+    if (live) {
+        if (MODE == BA_GLOBAL) {
+            i = n;
+            j = m;
+            cur = hb[(size_t)m * 64];
+            score = (int64_t)cur - (int64_t)g * (n + m);
+        } else if (MODE == BA_LOCAL) {
+            const BaLocalBest bb = P.best[B.first + lane];
+            score = bb.score;
+            if (bb.score > 0) {
+                // first column of row bb.i that reaches the maximum: rebuild the row's
+                // exact scores left to right from their residues (H(i,0) = 0)
+                const int t = bb.i - 1 + front;
+                const int rb = t / F, sh = (t % F) * K;
+                int v = 0;
+                for (int cg = 0; cg < cgs && j == 0; ++cg) {
+                    const uint4 q = block_words(rb, cg);
+                    const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t rho = (wd[c] >> sh) & MASK;
+                        v = v + (int)((rho - (uint32_t)v + (uint32_t)off) & MASK) - off;
+                        if (j == 0 && cg * 4 + c < m && v == bb.score) j = cg * 4 + c + 1;
+                    }
+                }
+                i = bb.i;
+                cur = bb.score;
+            }
+        } else {
+            // leftmost strict maximum of the bottom row, scan from column 0 (align_pair.go:169-182)
+            i = n;
+            cur = hb[0];
+            score = (int64_t)cur - (int64_t)g * n;
             for (int jj = 1; jj <= m; ++jj) {
-                const uint32_t rho = win.get(i, jj);
-                v = v + (int)(((uint32_t)(rho - (uint32_t)v + (uint32_t)off)) & MASK) - off;
-                if (v == bb.score) {
+                const int hv = hb[(size_t)jj * 64];
+                const int64_t v = (int64_t)hv - (int64_t)g * (n + jj);
+                if (v > score) {
+                    score = v;
                     j = jj;
-                    break;
+                    cur = hv;
                 }
             }
-            cur = bb.score;
-        } else {
-            i = 0;
         }
-    } else {
-        // leftmost strict maximum of the bottom row, scan from column 0 (align_pair.go:169-182)
-        i = n;
-        j = 0;
-        cur = hb[0];
-        score = (int64_t)cur - (int64_t)g * n;
-        for (int jj = 1; jj <= m; ++jj) {
-            const int hv = hb[(size_t)jj * 64];
-            const int64_t v = (int64_t)hv - (int64_t)g * (n + jj);
-            if (v > score) {
-                score = v;
-                j = jj;
-                cur = hv;
-            }
-        }
+        P.scores[p] = score;
     }
-    P.scores[p] = score;
     if (P.score_only) return;
 
     const uint64_t slot = o1 + o2;
@@ -502,76 +500,125 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     w2.init(P.t2, slot + cap);
     const uint32_t gs = P.gap_symbol;
     const int wbias = (MODE == BA_LOCAL) ? 0 : 2 * g;
+    const int b_top = (MODE == BA_FITTING) ? g : 0;   // Hs(0, j) = b_top * j
+    const int b_left = (MODE == BA_OVERLAP) ? g : 0;  // Hs(i, 0) = b_left * i
 
-    while (i > 0 || j > 0) {
-        int mv;  // 0 up, 1 left, 2 diagonal
-        int nxt = 0;
-        uint32_t x = 0, y = 0;
-        if (i == 0) {
-            if (top_free) break;
-            mv = 1;
-            nxt = 0;  // global / overlap: Hs(0, j-1) = 0
-        } else if (j == 0) {
-            if (left_free) break;
-            mv = 0;
-            nxt = 0;  // global / fitting: Hs(i-1, 0) = 0
-        } else {
-            if (MODE == BA_LOCAL && cur == 0) break;
-            // exact neighbours from residues (borders by formula)
-            int up, left, diag;
-            if (i == 1)
-                up = (MODE == BA_FITTING) ? g * j : 0;
-            else
-                up = cur - ((int)(((uint32_t)cur - win.get(i - 1, j) + (uint32_t)off) & MASK) - off);
-            if (j == 1)
-                left = (MODE == BA_OVERLAP) ? g * i : 0;
-            else
-                left = cur - ((int)(((uint32_t)cur - win.get(i, j - 1) + (uint32_t)off) & MASK) - off);
-            if (i == 1)
-                diag = (MODE == BA_FITTING) ? g * (j - 1) : 0;
-            else if (j == 1)
-                diag = (MODE == BA_OVERLAP) ? g * (i - 1) : 0;
-            else  // left neighbour of (i-1, j)
-                diag = up - ((int)(((uint32_t)up - win.get(i - 1, j - 1) + (uint32_t)off) & MASK) - off);
-            x = c1.get(i - 1);
-            y = c2.get(j - 1);
-            const int w = tbl[(int)code1[x] * P.nb + (int)code2[y]] + wbias;
-            const int d = diag + w;
-            const int mx = (MODE == BA_LOCAL) ? max(up, left) - g : max(up, left);
-            if (d > mx) {
-                mv = 2;
-                nxt = diag;
-            } else if (left > up) {
-                mv = 1;
-                nxt = left;
-            } else {
-                mv = 0;
-                nxt = up;
+    bool done = !live || (i == 0 && j == 0);
+    // band bookkeeping, per lane: which row block each of the two LDS bands holds and its first column
+    int tag0 = -1, tag1 = -1, col00 = 0, col01 = 0;
+    int sel = 0;  // uniform: which LDS band belongs to the current row block
+
+    // stage the band of row block rb that ends at the column group of column index `col` (0-based)
+    auto load_band = [&](int which, int rb, int col) {
+        const int cg_hi = col >> 2;
+        uint4 q[BG];
+#pragma unroll
+        for (int k = 0; k < BG; ++k) {
+            const int cg = cg_hi - (BG - 1) + k;
+            q[k] = cg >= 0 ? block_words(rb, cg) : make_uint4(0, 0, 0, 0);
+        }
+        uint32_t *dst = band + (size_t)which * BW * 64;
+#pragma unroll
+        for (int k = 0; k < BG; ++k) {
+            dst[(k * 4 + 0) * 64] = q[k].x;
+            dst[(k * 4 + 1) * 64] = q[k].y;
+            dst[(k * 4 + 2) * 64] = q[k].z;
+            dst[(k * 4 + 3) * 64] = q[k].w;
+        }
+        return (cg_hi - (BG - 1)) * 4;  // first column of the band
+    };
+
+    // rows n .. 1, all lanes in step
+    int i_top = i;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) i_top = max(i_top, __shfl_xor(i_top, d));
+    int last_rb = -1;
+    for (int iu = i_top; iu >= 1; --iu) {
+        const int t = iu - 1 + front;
+        const int rb = t / F, f = t % F;
+        if (rb != last_rb) {  // uniform: the band staged as "above" becomes the current one
+            sel ^= 1;
+            last_rb = rb;
+        }
+        const bool need_above = (f == 0) && (iu > 1);  // uniform: row iu-1 lies in row block rb-1
+        // lanes take their left moves, then leave the row by an up or a diagonal move
+        while (true) {
+            const bool act = !done && i == iu;
+            if (!__any(act)) break;
+            if (act) {
+                if (j == 0) {
+                    if (left_free) {
+                        done = true;
+                    } else {  // left border of global / fitting: forced up move, Hs(i-1, 0) = 0
+                        w1.put(c1.get(i - 1));
+                        w2.put(gs);
+                        --i;
+                        cur = 0;
+                    }
+                } else if (MODE == BA_LOCAL && cur == 0) {
+                    done = true;
+                } else {
+                    // bands: the current row block, and the one above while f == 0
+                    const int cl = max(j - 2, 0);  // leftmost column index (0-based) this step reads
+                    int tagc = sel ? tag1 : tag0, colc = sel ? col01 : col00;
+                    if (tagc != rb || cl < colc) {
+                        colc = load_band(sel, rb, j - 1);
+                        tagc = rb;
+                        if (sel) { tag1 = tagc; col01 = colc; } else { tag0 = tagc; col00 = colc; }
+                    }
+                    const uint32_t *bc = band + (size_t)sel * BW * 64;
+                    const uint32_t A = bc[(j - 1 - colc) * 64];
+                    const uint32_t Bw = bc[(cl - colc) * 64];
+                    uint32_t r_up, r_diag;
+                    if (need_above) {
+                        int taga = sel ? tag0 : tag1, cola = sel ? col00 : col01;
+                        if (taga != rb - 1 || cl < cola) {
+                            cola = load_band(sel ^ 1, rb - 1, j - 1);
+                            taga = rb - 1;
+                            if (sel) { tag0 = taga; col00 = cola; } else { tag1 = taga; col01 = cola; }
+                        }
+                        const uint32_t *ba = band + (size_t)(sel ^ 1) * BW * 64;
+                        r_up = (ba[(j - 1 - cola) * 64] >> ((F - 1) * K)) & MASK;
+                        r_diag = (ba[(cl - cola) * 64] >> ((F - 1) * K)) & MASK;
+                    } else {
+                        const int shu = (f > 0 ? f - 1 : 0) * K;
+                        r_up = (A >> shu) & MASK;
+                        r_diag = (Bw >> shu) & MASK;
+                    }
+                    const uint32_t r_left = (Bw >> (f * K)) & MASK;
+                    const int up = (iu == 1) ? b_top * j : neighbour(cur, r_up);
+                    const int left = (j == 1) ? b_left * iu : neighbour(cur, r_left);
+                    const int diag = (iu == 1) ? b_top * (j - 1) : (j == 1) ? b_left * (iu - 1) : neighbour(up, r_diag);
+                    const uint32_t x = c1.get(i - 1);
+                    const uint32_t y = c2.get(j - 1);
+                    const int w = tbl[(int)code1[x] * P.nb + (int)code2[y]] + wbias;
+                    const int d = diag + w;
+                    const int mx = (MODE == BA_LOCAL) ? max(up, left) - g : max(up, left);
+                    const int mv = d > mx ? 2 : (left > up ? 1 : 0);  // 0 up, 1 left, 2 diagonal
+                    cur = d > mx ? diag : (left > up ? left : up);
+                    w1.put(mv == 1 ? gs : x);
+                    w2.put(mv == 0 ? gs : y);
+                    i -= (mv != 1);
+                    j -= (mv != 0);
+                }
             }
         }
-        if (mv == 0) {
-            if (j == 0) x = c1.get(i - 1);
-            w1.put(x);
-            w2.put(gs);
-            --i;
-        } else if (mv == 1) {
-            if (i == 0) y = c2.get(j - 1);
+    }
+    // row 0: global / overlap walk left along the top border; local / fitting stop there
+    if (!done && !top_free) {
+        while (j > 0) {
             w1.put(gs);
-            w2.put(y);
-            --j;
-        } else {
-            w1.put(x);
-            w2.put(y);
-            --i;
+            w2.put(c2.get(j - 1));
             --j;
         }
-        cur = nxt;
     }
-    w1.flush();
-    w2.flush();
-    const uint64_t len = w1.end - w1.a;
-    P.t_off[p] = slot + cap - len;
-    P.t_len[p] = len;
+    if (live) {
+        w1.finish();
+        w2.finish();
+        const uint64_t len = (uint64_t)w1.length();
+        P.t_off[p] = slot + cap - len;
+        P.t_len[p] = len;
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -628,7 +675,8 @@ extern "C" hipError_t ba_launch_dp_linear(const BaDpParams &P, int mode, int R, 
 extern "C" size_t ba_trace_linear_lds_bytes(int na, int nb, int R, int K, int waves)
 {
     const int tbl = (na * nb + 3) & ~3;
-    const int words = 4 * (4 * (R * K / 32)) + 4;
+    const int F = 32 / K;
+    const int words = 2 * (F / 4 + 2) * 4;  // BaTraceGeom::WORDS
     return ((size_t)tbl + 128 + (size_t)waves * words * 64) * 4;
 }
 
