@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbioalign.so")
+LIB_PATH = os.environ.get("BIOALIGN_LIB") or os.path.join(_HERE, "lib", "libbioalign.so")  # override: A/B builds
 
 GLOBAL, LOCAL, FITTING, OVERLAP = 0, 1, 2, 3
 MODES = {"global": GLOBAL, "local": LOCAL, "fitting": FITTING, "overlap": OVERLAP}

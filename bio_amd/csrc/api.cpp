@@ -398,11 +398,8 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         pk.s2 = d_s2;
         pk.s1_off = d_s1_off;
         pk.s2_off = d_s2_off;
-        pk.code1 = pl->d_code1;
-        pk.code2 = pl->d_code2;
         pk.s1w = pl->d_s1w;
         pk.s2w = pl->d_s2w;
-        pk.pad_code = (uint32_t)pl->na;
         pk.rows_per_strip = pl->R;
         HIP_TRY(ctx, ba_launch_pack(pk, st));
 
@@ -416,6 +413,9 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         dp.dir = pl->d_dir;
         dp.best = pl->d_best;
         dp.wt = pl->d_wt;
+        dp.code1 = pl->d_code1;
+        dp.code2 = pl->d_code2;
+        dp.pad_code = pl->na;
         dp.nb = pl->nb;
         dp.nb4 = pl->nb4;
         dp.na_pad = pl->na_pad;
@@ -444,6 +444,8 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         tr.table = pl->d_table;
         tr.na = pl->na;
         tr.nb = pl->nb;
+        tr.s1w = pl->d_s1w;
+        tr.s2w = pl->d_s2w;
         tr.hb = pl->d_hb;
         tr.dir = pl->d_dir;
         tr.best = pl->d_best;

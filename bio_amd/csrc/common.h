@@ -23,8 +23,8 @@ struct BaBundle {
     uint32_t n, m;     // len(s1), len(s2) of every pair in the bundle
     uint32_t first;    // first position in the shape-sorted pair order
     uint32_t count;    // pairs in the bundle (1..64)
-    uint64_t s1w_off;  // dword offset of the bundle's packed s1 code words
-    uint64_t s2w_off;  // dword offset of the bundle's packed s2 code words
+    uint64_t s1w_off;  // dword offset of the bundle's lane-interleaved s1 words (raw bytes, front padded)
+    uint64_t s2w_off;  // dword offset of the bundle's lane-interleaved s2 words (raw bytes)
     uint64_t hb_off;   // int32 offset of the bundle's boundary row
     uint64_t dir_off;  // dword offset of the bundle's direction words
 };
@@ -42,9 +42,7 @@ struct BaPackParams {
     const uint32_t *perm;      // shape-sorted order -> caller's pair index
     const uint8_t *s1, *s2;    // caller's concatenated bytes (device)
     const uint64_t *s1_off, *s2_off;
-    const uint8_t *code1, *code2;  // [256] byte -> dense code
     uint32_t *s1w, *s2w;
-    uint32_t pad_code;         // s1-side code of the padding rows
     int rows_per_strip;
 };
 
@@ -56,6 +54,8 @@ struct BaDpParams {
     uint32_t *dir;
     BaLocalBest *best;     // indexed by sorted position
     const uint32_t *wt;    // transposed int8 score table, dwords [nb4][na_pad]
+    const uint8_t *code1, *code2;  // [256] byte -> dense code (256-byte aligned device arrays)
+    int pad_code;          // s1-side code of the rows above the matrix
     int nb, nb4, na_pad;
     int gap;               // linear gap penalty (>= 0 on this path)
     int gap_open, gap_ext; // affine
@@ -70,6 +70,7 @@ struct BaTraceParams {
     const uint8_t *code1, *code2;
     const int32_t *table;  // na * nb scores, as the caller gave them
     int na, nb;
+    const uint32_t *s1w, *s2w;  // lane-interleaved raw bytes (pack kernel)
     const int32_t *hb;
     const uint32_t *dir;
     const BaLocalBest *best;

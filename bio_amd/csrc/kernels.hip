@@ -52,53 +52,92 @@ __device__ __forceinline__ uint32_t ba_push_residue(uint32_t acc, int x)
 }
 
 // ----------------------------------------------------------------------------
-// pack: caller bytes -> dense codes, lane-interleaved words
-//   word k of lane l of a bundle lives at  w_off + k*64 + l  (4 codes per word)
+// pack: caller bytes -> lane-interleaved words of RAW bytes (4 symbols per word)
+//   word k of lane l of a bundle lives at  w_off + k*64 + l
+// s1 is padded at the FRONT up to a whole number of strips (the DP kernel gives
+// those rows the padding code); s2 is padded at the back of its last word.
+// One lane = one pair: a lane walks its own sequence with 4-byte loads (the
+// consecutive words of a pair share cache lines) and the wavefront's stores are
+// full 256-byte lines.
 // ----------------------------------------------------------------------------
+// Bytes src[pos .. pos+3] of a sequence of `len` > 0 bytes that starts `so` bytes
+// into the 4-byte-aligned array `ab`, from ALIGNED dword loads only (unaligned
+// dword loads run at a fraction of the aligned rate on gfx950: 0.37 TB/s measured
+// for this kernel).  Positions outside [0, len) come back as arbitrary bytes (no
+// consumer looks at them); the two loads are clamped to the dwords that hold the
+// sequence's first and last byte, so nothing outside the sequence's own dwords is
+// ever touched.
+__device__ __forceinline__ uint32_t ba_load4(const uint8_t *ab, int64_t so, int pos, int len)
+{
+    const int64_t first = so & ~(int64_t)3, last = (so + len - 1) & ~(int64_t)3;
+    const int64_t ad = so + pos;
+    const int64_t al = ad & ~(int64_t)3;
+    const int64_t p0 = min(max(al, first), last), p1 = min(max(al + 4, first), last);
+    const uint32_t lo = *reinterpret_cast<const uint32_t *>(ab + p0);
+    const uint32_t hi = *reinterpret_cast<const uint32_t *>(ab + p1);
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(ad & 3) * 8);
+}
+
+// One wavefront transposes one bundle through an LDS tile of 64 pairs x 256
+// bytes: reading, the whole wavefront takes 256 consecutive bytes of ONE pair
+// per instruction (coalesced); writing, lane l emits its own pair's words, so a
+// store instruction is one full 256-byte line of the interleaved layout.
+// Tile rows are 65 words apart: both phases are bank-conflict free.
+template <bool FRONT_PADDED>
+__device__ __forceinline__ void ba_pack_side(const uint8_t *base, uint64_t mine, int len, int shift, int nwords,
+                                             int count, uint32_t *tile, uint32_t *out, int lane)
+{
+    // `mine` is this lane's pair's byte offset into `base`.
+    // output word k holds source bytes 4k-shift .. 4k-shift+3 (zero outside [0, len))
+    const uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
+    const int mis = (int)((uint64_t)base & 3);
+    const uint8_t *ab = base - mis;
+    if (len == 0) {  // bundle-uniform: nothing to read (s2 has no words; s1's are all padding)
+        for (int k = 0; k < nwords; ++k) out[(size_t)k * 64] = 0u;
+        return;
+    }
+    for (int k0 = 0; k0 < nwords; k0 += 64) {
+        const int kw = min(64, nwords - k0);
+        // 16 pairs per round, so that 32 independent loads are in flight per lane
+        for (int q0 = 0; q0 < count; q0 += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int q = min(q0 + u, count - 1);
+                // (readlane returns int: go through uint32_t, or the low half sign-extends over the high one)
+                const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, q) << 32) |
+                                     (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)lo, q);
+                // unconditional (addresses are clamped into the sequence): no branch, so the
+                // loads of a round issue back to back and one wait covers them all
+                v[u] = ba_load4(ab, (int64_t)off + mis, 4 * (k0 + lane) - shift, len);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (q0 + u < count && lane < kw) tile[(q0 + u) * 65 + lane] = v[u];
+        }
+        // each lane reads back only its own row, after its own wavefront wrote it: LDS
+        // operations of one wavefront complete in order, no barrier needed
+        for (int k = 0; k < kw; ++k) out[(size_t)(k0 + k) * 64] = lane < count ? tile[lane * 65 + k] : 0u;
+    }
+}
+
 __global__ void __launch_bounds__(256) ba_pack_kernel(BaPackParams P)
 {
-    const uint32_t b_idx = P.bundle_begin + blockIdx.x;
+    __shared__ uint32_t tiles[4][64 * 65];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t b_idx = P.bundle_begin + blockIdx.x * 4 + wave;
     if (b_idx >= P.bundle_end) return;
     const BaBundle B = P.bundles[b_idx];
-    const uint32_t R = P.rows_per_strip;
-    const uint32_t strips = (B.n + R - 1) / R;
-    const uint32_t nw1 = strips * R / 4;
-    const uint32_t nw2 = (B.m + 3) / 4;
-    // s1 is padded at the FRONT up to a whole number of strips: the last strip
-    // then always ends on the matrix's last row (see ba_dp_linear_kernel)
-    const uint32_t front = strips * R - B.n;
-    const uint32_t padword = P.pad_code * 0x01010101u;
-    for (uint32_t idx = threadIdx.x; idx < (nw1 + nw2) * 64; idx += blockDim.x) {
-        const bool side2 = idx >= nw1 * 64;
-        const uint32_t rel = side2 ? idx - nw1 * 64 : idx;
-        const uint32_t k = rel >> 6, l = rel & 63;
-        uint32_t word = side2 ? 0u : padword;
-        if (l < B.count) {
-            const uint32_t p = P.perm[B.first + l];
-            word = 0;
-            if (side2) {
-                const uint8_t *src = P.s2 + P.s2_off[p];
-#pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) {
-                    const uint32_t pos = 4 * k + q;
-                    const uint32_t c = pos < B.m ? (uint32_t)P.code2[src[pos]] : 0u;
-                    word |= c << (8 * q);
-                }
-            } else {
-                const uint8_t *src = P.s1 + P.s1_off[p];
-#pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) {
-                    const uint32_t t = 4 * k + q;
-                    const uint32_t c = t >= front ? (uint32_t)P.code1[src[t - front]] : P.pad_code;
-                    word |= c << (8 * q);
-                }
-            }
-        }
-        if (side2)
-            P.s2w[B.s2w_off + rel] = word;
-        else
-            P.s1w[B.s1w_off + rel] = word;
-    }
+    const int R = P.rows_per_strip;
+    const int n = (int)B.n, m = (int)B.m;
+    const int strips = (n + R - 1) / R;
+    const int front = strips * R - n;
+    const bool live = lane < (int)B.count;
+    const uint32_t p = live ? P.perm[B.first + lane] : 0u;
+    const uint64_t a1 = live ? P.s1_off[p] : 0, a2 = live ? P.s2_off[p] : 0;
+    ba_pack_side<true>(P.s1, a1, n, front, strips * R / 4, (int)B.count, tiles[wave], P.s1w + B.s1w_off + lane, lane);
+    ba_pack_side<false>(P.s2, a2, m, 0, (m + 3) / 4, (int)B.count, tiles[wave], P.s2w + B.s2w_off + lane, lane);
 }
 
 // ----------------------------------------------------------------------------
@@ -147,9 +186,15 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves = blockDim.x >> 6;
 
-    // the transposed int8 score table, shared by the block
+    // the transposed int8 score table and the byte -> code maps, shared by the block
     const int wt_words = P.nb4 * P.na_pad;
+    const int wt_aligned = (wt_words + 3) & ~3;
     for (int i = threadIdx.x; i < wt_words; i += blockDim.x) lds[i] = P.wt[i];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x)
+        lds[wt_aligned + i] = i < 64 ? reinterpret_cast<const uint32_t *>(P.code1)[i]
+                                     : reinterpret_cast<const uint32_t *>(P.code2)[i - 64];
+    const uint8_t *code1 = reinterpret_cast<const uint8_t *>(lds + wt_aligned);
+    const uint8_t *code2 = code1 + 256;
     __syncthreads();
 
     const uint32_t b_idx = P.bundle_begin + blockIdx.x * waves + wave;
@@ -159,9 +204,9 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
     const int g = P.gap;
     const int strips = (n + R - 1) / R;
     const int cgs = (m + 3) / 4;
+    const int front = strips * R - n;
 
-    const int wt_aligned = (wt_words + 3) & ~3;
-    uint8_t *prof = reinterpret_cast<uint8_t *>(lds + wt_aligned) + (size_t)wave * P.nb * (HALVES * 64 * 16);
+    uint8_t *prof = reinterpret_cast<uint8_t *>(lds + wt_aligned + 128) + (size_t)wave * P.nb * (HALVES * 64 * 16);
     uint8_t *prof_lane = prof + lane * 16;
 
     int32_t *hb = P.hb + B.hb_off + lane;
@@ -194,11 +239,13 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
                 uint32_t o[4][4];
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
+                    // rows of the strip that lie above the matrix (t < front) take the padding code
                     const uint32_t wq = aw[hf * 4 + q4];
-                    const uint32_t t0 = wrow[wq & 0xffu];
-                    const uint32_t t1 = wrow[(wq >> 8) & 0xffu];
-                    const uint32_t t2 = wrow[(wq >> 16) & 0xffu];
-                    const uint32_t t3 = wrow[wq >> 24];
+                    const int tq = s * R + (hf * 4 + q4) * 4;
+                    const uint32_t t0 = wrow[tq + 0 >= front ? (uint32_t)code1[wq & 0xffu] : (uint32_t)P.pad_code];
+                    const uint32_t t1 = wrow[tq + 1 >= front ? (uint32_t)code1[(wq >> 8) & 0xffu] : (uint32_t)P.pad_code];
+                    const uint32_t t2 = wrow[tq + 2 >= front ? (uint32_t)code1[(wq >> 16) & 0xffu] : (uint32_t)P.pad_code];
+                    const uint32_t t3 = wrow[tq + 3 >= front ? (uint32_t)code1[wq >> 24] : (uint32_t)P.pad_code];
                     // 4x4 byte transpose: o[bb] = {t0.bb, t1.bb, t2.bb, t3.bb}
                     const uint32_t lo01 = __builtin_amdgcn_perm(t1, t0, 0x05010400u);  // t0.0 t1.0 t0.1 t1.1
                     const uint32_t hi01 = __builtin_amdgcn_perm(t1, t0, 0x07030602u);  // t0.2 t1.2 t0.3 t1.3
@@ -239,13 +286,16 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
             constexpr bool FULL = decltype(full)::value;
             const uint32_t sw = s2w[(size_t)cg * 64];
             const int jbase = cg * 4 + 1;
+            uint32_t bcode[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bcode[c] = code2[(sw >> (c * 8)) & 0xffu];
             int tops[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) tops[c] = (FULL || jbase + c <= m) ? hb[(size_t)(jbase + c) * 64] : 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (FULL || jbase + c <= m) {
-                    const uint32_t b = (sw >> (c * 8)) & 0xffu;
+                    const uint32_t b = bcode[c];
                     const uint4 *pp = reinterpret_cast<const uint4 *>(prof_lane + (size_t)b * (HALVES * 64 * 16));
                     uint32_t pw[R / 4];
 #pragma unroll
@@ -305,82 +355,67 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
 // while the row is the first of its block, the band of the block above.  LDS
 // words are lane-interleaved ([word][lane]): any per-lane index is conflict free.
 
-// byte `idx` of a byte array through a one-dword register cache.  Loads are
-// aligned dwords (an aligned dword that contains a valid byte never leaves that
-// byte's page) addressed from the kernel-argument pointer, so they stay
-// global_load (not flat_load) instructions.
-struct BaByteCache {
-    const uint8_t *abase;  // array base rounded down to 4 bytes
-    int mis;               // array base - abase
-    int tag;               // dword index (from abase) held in `word`
-    uint32_t word;
-    __device__ __forceinline__ void init(const uint8_t *p)
-    {
-        mis = (int)((uint64_t)p & 3);
-        abase = p - mis;
-        tag = -1;
-        word = 0;
-    }
-    __device__ __forceinline__ uint32_t get(int idx)
-    {
-        const int pos = idx + mis;
-        const int dw = pos >> 2;
-        if (dw != tag) {
-            word = *reinterpret_cast<const uint32_t *>(abase + (size_t)dw * 4);
-            tag = dw;
-            // consume the value inside the branch, so that the wait for it stays in
-            // here and no s_waitcnt is executed on the (usual) hit path
-            asm volatile("" : "+v"(word));
-        }
-        return (word >> ((pos & 3) * 8)) & 0xffu;
-    }
-};
-
-// Writes bytes back to front.  Bytes are collected per aligned dword and go out
-// as one dword store.  The two dwords that can be shared with a neighbouring
-// slot -- the one holding the slot's end and the one holding the trace's first
-// byte -- are written byte by byte at the end (finish()).
+// Writes bytes back to front through a 16-byte shift register: a new byte (the
+// lowest address so far) enters at byte 0 and the rest moves up, so byte k of
+// the register always belongs to address a+k.  Every time the write position
+// reaches a 16-byte boundary the register is exactly that block and goes out as
+// one dwordx4 store.  The two blocks that can be shared with a neighbouring slot
+// -- the one holding the slot's end and the one holding the trace's first byte
+// -- are written byte by byte in finish().
 struct BaBackWriter {
-    uint8_t *abase;    // buffer base rounded down to 4 bytes
-    int64_t end;       // offset (from abase) one past the slot
-    int64_t a;         // offset of the last byte written (== end when empty)
-    uint32_t word;     // bytes collected for the aligned dword that contains a
-    uint32_t topword;  // the collected dword that holds the slot's end, if it is partial
+    uint8_t *abase;            // buffer base rounded down to 16 bytes
+    int64_t end;               // offset (from abase) one past the slot
+    int64_t a;                 // offset of the last byte written (== end when empty)
+    uint32_t w0, w1, w2, w3;   // shift register: byte k <-> address a + k
+    uint32_t t0, t1, t2, t3;   // the register as it was for the (partial) block that holds the slot's end
     __device__ __forceinline__ void init(uint8_t *buf, uint64_t end_index)
     {
-        const int mis = (int)((uint64_t)buf & 3);
+        const int mis = (int)((uint64_t)buf & 15);
         abase = buf - mis;
         end = (int64_t)end_index + mis;
         a = end;
-        word = 0;
-        topword = 0;
+        w0 = w1 = w2 = w3 = 0;
+        t0 = t1 = t2 = t3 = 0;
     }
     __device__ __forceinline__ void put(uint32_t byte)
     {
         --a;
-        word |= byte << ((uint32_t)(a & 3) * 8);
-        if ((a & 3) == 0) {
-            if (a + 4 <= end)
-                *reinterpret_cast<uint32_t *>(abase + a) = word;
-            else
-                topword = word;
-            word = 0;
+        w3 = __builtin_amdgcn_alignbit(w3, w2, 24);
+        w2 = __builtin_amdgcn_alignbit(w2, w1, 24);
+        w1 = __builtin_amdgcn_alignbit(w1, w0, 24);
+        w0 = (w0 << 8) | byte;
+        if ((a & 15) == 0) {
+            if (a + 16 <= end) {
+#ifndef BA_EXP_NOSTORE
+                *reinterpret_cast<uint4 *>(abase + a) = make_uint4(w0, w1, w2, w3);
+#endif
+            } else {
+                t0 = w0; t1 = w1; t2 = w2; t3 = w3;
+            }
         }
     }
     __device__ __forceinline__ int64_t length() const { return end - a; }
+    // abase[lo + k] = byte k of (r0..r3) for lo + k < hi
+    static __device__ __forceinline__ void write_bytes(uint8_t *abase, int64_t lo, int64_t hi,
+                                                      uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3)
+    {
+        for (int64_t q = lo; q < hi; ++q) {
+            abase[q] = (uint8_t)r0;
+            r0 = __builtin_amdgcn_alignbit(r1, r0, 8);
+            r1 = __builtin_amdgcn_alignbit(r2, r1, 8);
+            r2 = __builtin_amdgcn_alignbit(r3, r2, 8);
+            r3 >>= 8;
+        }
+    }
     __device__ __forceinline__ void finish()
     {
-        const int64_t top_al = end & ~(int64_t)3;  // start of the dword that holds the slot's end
-        if (a & 3) {                               // partial dword at the front of the trace
-            const int64_t al = a & ~(int64_t)3;
-            if (al == top_al) topword = word;  // the trace never left the end dword
-            else
-                for (int64_t q = a; q < al + 4; ++q) abase[q] = (uint8_t)(word >> ((uint32_t)(q & 3) * 8));
+        const int64_t top_blk = end & ~(int64_t)15;  // block that holds the slot's end (partial if end & 15)
+        if (a & 15) {                                // partial block at the front of the trace
+            const int64_t blk = a & ~(int64_t)15;
+            write_bytes(abase, a, blk + 16 < end ? blk + 16 : end, w0, w1, w2, w3);
+            if (blk == top_blk) return;  // the trace never left the end block
         }
-        if (end & 3) {
-            const int64_t lo = a > top_al ? a : top_al;
-            for (int64_t q = lo; q < end; ++q) abase[q] = (uint8_t)(topword >> ((uint32_t)(q & 3) * 8));
-        }
+        if ((end & 15) && a <= top_blk) write_bytes(abase, top_blk, end, t0, t1, t2, t3);
     }
 };
 
@@ -492,9 +527,30 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
 
     const uint64_t slot = o1 + o2;
     const uint64_t cap = (uint64_t)n + (uint64_t)m;
-    BaByteCache c1, c2;
-    c1.init(P.s1 + o1);
-    c2.init(P.s2 + o2);
+    // sequence symbols come from the pack kernel's lane-interleaved raw words: a row is
+    // the same word index in every lane (one coalesced line per 4 rows); columns differ
+    // per lane but neighbouring lanes stay close
+    const uint32_t *s1w = P.s1w + B.s1w_off + lane;
+    const uint32_t *s2w = P.s2w + B.s2w_off + lane;
+    int k1_tag = -1, k2_tag = -1;
+    uint32_t x_word = 0, y_word = 0;
+    auto sym1 = [&](int i1) {  // s1[i1-1]; i1 is wave-uniform
+        const int t = i1 - 1 + front;
+        if ((t >> 2) != k1_tag) {
+            k1_tag = t >> 2;
+            x_word = s1w[(size_t)k1_tag * 64];
+        }
+        return (x_word >> ((t & 3) * 8)) & 0xffu;
+    };
+    auto sym2 = [&](int j1) {  // s2[j1-1]
+        const int c = j1 - 1;
+        if ((c >> 2) != k2_tag) {
+            k2_tag = c >> 2;
+            y_word = s2w[(size_t)k2_tag * 64];
+            asm volatile("" : "+v"(y_word));  // keep the wait for the load inside this branch
+        }
+        return (y_word >> ((c & 3) * 8)) & 0xffu;
+    };
     BaBackWriter w1, w2;
     w1.init(P.t1, slot + cap);
     w2.init(P.t2, slot + cap);
@@ -541,6 +597,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
             last_rb = rb;
         }
         const bool need_above = (f == 0) && (iu > 1);  // uniform: row iu-1 lies in row block rb-1
+        const uint32_t x_row = sym1(iu);                // s1[iu-1] of every lane
         // lanes take their left moves, then leave the row by an up or a diagonal move
         while (true) {
             const bool act = !done && i == iu;
@@ -550,7 +607,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
                     if (left_free) {
                         done = true;
                     } else {  // left border of global / fitting: forced up move, Hs(i-1, 0) = 0
-                        w1.put(c1.get(i - 1));
+                        w1.put(x_row);
                         w2.put(gs);
                         --i;
                         cur = 0;
@@ -589,8 +646,8 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
                     const int up = (iu == 1) ? b_top * j : neighbour(cur, r_up);
                     const int left = (j == 1) ? b_left * iu : neighbour(cur, r_left);
                     const int diag = (iu == 1) ? b_top * (j - 1) : (j == 1) ? b_left * (iu - 1) : neighbour(up, r_diag);
-                    const uint32_t x = c1.get(i - 1);
-                    const uint32_t y = c2.get(j - 1);
+                    const uint32_t x = x_row;
+                    const uint32_t y = sym2(j);
                     const int w = tbl[(int)code1[x] * P.nb + (int)code2[y]] + wbias;
                     const int d = diag + w;
                     const int mx = (MODE == BA_LOCAL) ? max(up, left) - g : max(up, left);
@@ -608,7 +665,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     if (!done && !top_free) {
         while (j > 0) {
             w1.put(gs);
-            w2.put(c2.get(j - 1));
+            w2.put(sym2(j));
             --j;
         }
     }
@@ -628,14 +685,14 @@ extern "C" size_t ba_dp_linear_lds_bytes(int nb, int nb4, int na_pad, int R, int
 {
     const int wt_words = nb4 * na_pad;
     const int wt_aligned = (wt_words + 3) & ~3;
-    return (size_t)wt_aligned * 4 + (size_t)waves * nb * (R / 16) * 64 * 16;
+    return (size_t)(wt_aligned + 128) * 4 + (size_t)waves * nb * (R / 16) * 64 * 16;
 }
 
 extern "C" hipError_t ba_launch_pack(const BaPackParams &P, hipStream_t st)
 {
     const uint32_t nb = P.bundle_end - P.bundle_begin;
     if (nb == 0) return hipSuccess;
-    hipLaunchKernelGGL(ba_pack_kernel, dim3(nb), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(ba_pack_kernel, dim3((nb + 3) / 4), dim3(256), 0, st, P);
     return hipGetLastError();
 }
 
