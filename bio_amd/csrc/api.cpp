@@ -277,7 +277,8 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         while (e < N && e - q < BA_WAVE && len1[perm[e]] == n && len2[perm[e]] == m) ++e;
         const uint64_t strips = (n + R - 1) / R;
         const uint64_t sz_s1w = strips * R / 4 * 64, sz_s2w = (uint64_t)((m + 3) / 4) * 64;
-        const uint64_t sz_hb = (uint64_t)(m + 1) * 64, sz_dir = strips * (uint64_t)((m + 3) / 4) * 64 * chw;
+        // boundary deltas: two buffers (strip parity) of ceil(m / F) words per lane, F >= 4
+        const uint64_t sz_hb = 2 * (uint64_t)((m + 3) / 4 + 1) * 64, sz_dir = strips * (uint64_t)((m + 3) / 4) * 64 * chw;
         const uint64_t after = (o_s1w + sz_s1w + o_s2w + sz_s2w + o_hb + sz_hb + o_dir + sz_dir) * 4;
         if (after > budget && pl->bundles.size() > chunk_begin) {
             pl->chunks.push_back({chunk_begin, (uint32_t)pl->bundles.size()});

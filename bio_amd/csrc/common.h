@@ -25,7 +25,7 @@ struct BaBundle {
     uint32_t count;    // pairs in the bundle (1..64)
     uint64_t s1w_off;  // dword offset of the bundle's lane-interleaved s1 words (raw bytes, front padded)
     uint64_t s2w_off;  // dword offset of the bundle's lane-interleaved s2 words (raw bytes)
-    uint64_t hb_off;   // int32 offset of the bundle's boundary row
+    uint64_t hb_off;   // dword offset of the bundle's boundary-delta words (strip hand-over row)
     uint64_t dir_off;  // dword offset of the bundle's direction words
 };
 

@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) ba_pack_kernel(BaPackParams P)
 // linear-gap DP: one column of one strip (R rows in VGPRs)
 // ----------------------------------------------------------------------------
 template <int MODE, int R, int K>
-__device__ __forceinline__ void ba_linear_column(int (&h)[R], int (&rmax)[R], uint32_t (&acc)[R * K / 32],
+__device__ __forceinline__ void ba_linear_column(int (&h)[R], int (&rmax)[R / 2], uint32_t (&acc)[R * K / 32],
                                                  const uint32_t (&pw)[R / 4], int top, int &topdiag, int g)
 {
     constexpr int F = 32 / K;  // residues per word
@@ -157,7 +157,8 @@ __device__ __forceinline__ void ba_linear_column(int (&h)[R], int (&rmax)[R], ui
         int hn;
         if (MODE == BA_LOCAL) {
             hn = ba_max3(max(up, left) - g, d, 0);
-            rmax[r] = max(rmax[r], hn);
+            // running maximum per PAIR of rows: one v_max3_i32 per two cells
+            if (r & 1) rmax[r / 2] = ba_max3(rmax[r / 2], up, hn);
         } else {
             hn = ba_max3(up, left, d);
         }
@@ -209,15 +210,20 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
     uint8_t *prof = reinterpret_cast<uint8_t *>(lds + wt_aligned + 128) + (size_t)wave * P.nb * (HALVES * 64 * 16);
     uint8_t *prof_lane = prof + lane * 16;
 
-    int32_t *hb = P.hb + B.hb_off + lane;
+    // boundary deltas: the row a strip hands to the next one, as K-bit horizontal
+    // differences (F columns per word, lane-interleaved, two buffers by strip parity)
+    constexpr int F = 32 / K;
+    constexpr uint32_t MASK = (1u << K) - 1u;
+    constexpr uint32_t REP = 0xffffffffu / MASK;  // every K-bit field = 1
+    const int nbw = (m + F - 1) / F;
+    uint32_t *bd = reinterpret_cast<uint32_t *>(P.hb) + B.hb_off + lane;
     uint32_t *dir = P.dir + B.dir_off + (size_t)lane * CHW;
     const uint32_t *s1w = P.s1w + B.s1w_off + lane;
     const uint32_t *s2w = P.s2w + B.s2w_off + lane;
+    const int off = (MODE == BA_LOCAL) ? g : 0;  // a horizontal step is never below -off
 
-    // row 0 (align.go:92-95, 175-177; align_pair.go:110-113, 158, 187) in the working space
-    for (int j = 0; j <= m; ++j) hb[(size_t)j * 64] = (MODE == BA_FITTING) ? g * j : 0;
-
-    int best_sc = 0, best_i = 0;
+    int best_sc = 0, best_i = 0, best_j = 0;  // local: maximum and its row pair; others: end cell
+    if (MODE == BA_GLOBAL) best_j = m;        // (strips == 0: row 0 is the bottom row, Hs(0, .) handled by the trace kernel)
 
     // Strips are aligned to the BOTTOM of the matrix: strip s covers matrix rows
     // i0+1 .. i0+R with i0 = n - (strips-s)*R, so the first strip may start with
@@ -227,6 +233,12 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
     // 1 sees the right border and the last strip always ends on row n.
     for (int s = 0; s < strips; ++s) {
         const int i0 = n - (strips - s) * R;
+        const bool last_strip = (s == strips - 1);
+        const uint32_t *bd_rd = bd + (size_t)((s + 1) & 1) * nbw * 64;
+        uint32_t *bd_wr = bd + (size_t)(s & 1) * nbw * 64;
+        // row above the first strip = row 0 (align.go:92-95, 175-177; align_pair.go:110-113, 158, 187):
+        // constant horizontal step in the working space
+        const uint32_t bd_row0 = (uint32_t)(((MODE == BA_FITTING) ? g : 0) + off) * REP;
         // codes of the strip's rows
         uint32_t aw[R / 4];
 #pragma unroll
@@ -266,32 +278,45 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
             }
         }
         // column 0 (align.go:99-100, 181; align_pair.go:113, 131, 159, 188) in the working space
-        int h[R], rmax[R];
+        int h[R], rmax[R / 2];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             h[r] = (MODE == BA_OVERLAP) ? g * max(i0 + r + 1, 0) : 0;
-            rmax[r] = 0;
+            rmax[r / 2] = 0;
         }
-        int topdiag = hb[0];
-        hb[0] = h[R - 1];
+        int topdiag = (MODE == BA_OVERLAP) ? g * max(i0, 0) : 0;  // Hs(i0, 0)
         uint32_t *dirs = dir + (size_t)s * cgs * (64 * CHW);
         uint32_t acc[4][WPC];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int w = 0; w < WPC; ++w) acc[c][w] = 0;
+        uint32_t accb = 0;  // boundary deltas of this strip's last row, being collected
+        // bottom row of the matrix: leftmost strict maximum of the UNBIASED scores, scan from
+        // column 0 (align_pair.go:169-182); unbiased = Hs(n, j) - g*j up to a constant
+        int end_v = h[R - 1], end_j = 0, end_cur = h[R - 1];
+        // What a column group needs from memory: its packed s2 word and the word of boundary
+        // deltas above it.  They are fetched one group AHEAD (the loads for group cg+1 are
+        // issued before group cg is computed), so their latency never sits on the critical path.
+        struct GroupIn {
+            uint32_t sw, bw;
+        };
+        auto fetch_group = [&](int cg) {
+            GroupIn gi;
+            gi.sw = s2w[(size_t)cg * 64];
+            gi.bw = bd_rd[(size_t)((cg * 4) / F) * 64];
+            return gi;
+        };
         // one group of 4 columns (one packed s2 word): FULL groups run without any
         // per-column test so that the strip stays in the same registers all along
-        auto column_group = [&](int cg, auto full) {
+        auto column_group = [&](int cg, const GroupIn &in, auto full) {
             constexpr bool FULL = decltype(full)::value;
-            const uint32_t sw = s2w[(size_t)cg * 64];
             const int jbase = cg * 4 + 1;
+            const uint32_t bw = (s == 0) ? bd_row0 : in.bw;
+            const int sh0 = ((cg * 4) % F) * K;  // uniform
             uint32_t bcode[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) bcode[c] = code2[(sw >> (c * 8)) & 0xffu];
-            int tops[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) tops[c] = (FULL || jbase + c <= m) ? hb[(size_t)(jbase + c) * 64] : 0;
+            for (int c = 0; c < 4; ++c) bcode[c] = code2[(in.sw >> (c * 8)) & 0xffu];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (FULL || jbase + c <= m) {
@@ -306,35 +331,69 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
                         pw[hf * 4 + 2] = v.z;
                         pw[hf * 4 + 3] = v.w;
                     }
-                    ba_linear_column<MODE, R, K>(h, rmax, acc[c], pw, tops[c], topdiag, g);
-                    hb[(size_t)(jbase + c) * 64] = h[R - 1];
+                    // score above this column = score above the previous one + the stored step
+                    const int top = topdiag + (int)((bw >> (sh0 + c * K)) & MASK) - off;
+                    const int old_last = h[R - 1];
+                    ba_linear_column<MODE, R, K>(h, rmax, acc[c], pw, top, topdiag, g);
+                    accb = __builtin_amdgcn_alignbit((uint32_t)(h[R - 1] - old_last + off), accb, K);
+                    if ((MODE == BA_FITTING || MODE == BA_OVERLAP) && last_strip) {
+                        const int v = h[R - 1] - g * (jbase + c);
+                        if (v > end_v) {
+                            end_v = v;
+                            end_j = jbase + c;
+                            end_cur = h[R - 1];
+                        }
+                    }
                 }
             }
             uint4 *dst = reinterpret_cast<uint4 *>(dirs + (size_t)cg * (64 * CHW));
 #pragma unroll
             for (int w = 0; w < WPC; ++w) dst[w] = make_uint4(acc[0][w], acc[1][w], acc[2][w], acc[3][w]);
+            if (FULL && !last_strip && ((cg + 1) * 4) % F == 0) bd_wr[(size_t)((cg * 4) / F) * 64] = accb;
         };
         const int full_groups = m / 4;
-        for (int cg = 0; cg < full_groups; ++cg) column_group(cg, std::true_type{});
-        if (full_groups < cgs) column_group(full_groups, std::false_type{});
+        if (cgs > 0) {
+            GroupIn nxt = fetch_group(0);
+            for (int cg = 0; cg < full_groups; ++cg) {
+                const GroupIn cur = nxt;
+                nxt = fetch_group(min(cg + 1, cgs - 1));
+                column_group(cg, cur, std::true_type{});
+            }
+            if (full_groups < cgs) column_group(full_groups, nxt, std::false_type{});
+            // the last, partial word of boundary deltas: its m % F fields sit at the top
+            if (!last_strip && (m % F) != 0) bd_wr[(size_t)(m / F) * 64] = accb >> ((F - m % F) * K);
+        }
+        if (last_strip && MODE != BA_LOCAL) {
+            if (MODE == BA_GLOBAL) {
+                best_sc = h[R - 1];  // Hs(n, m)
+                best_i = n;
+                best_j = m;
+            } else {
+                best_sc = end_cur;
+                best_i = n;
+                best_j = end_j;
+            }
+        }
         if (MODE == BA_LOCAL) {
-            // first row (ascending) that holds the strict maximum (align.go:216-221);
-            // the traceback kernel finds the first column of that row.  Rows i <= 0
-            // score 0 everywhere and never win.
+            // first PAIR of rows (ascending) that holds the strict maximum (align.go:216-221);
+            // the traceback kernel finds the first cell of that pair in row-major order.
+            // Rows i <= 0 score 0 everywhere and never win.
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (rmax[r] > best_sc) {
-                    best_sc = rmax[r];
-                    best_i = i0 + r + 1;
+            for (int r = 0; r < R; r += 2) {
+                if (rmax[r / 2] > best_sc) {
+                    best_sc = rmax[r / 2];
+                    best_i = i0 + r + 1;  // first row of the pair (may be <= 0 only with a zero score)
                 }
             }
         }
     }
-    if (MODE == BA_LOCAL && lane < (int)B.count) {
+    // end cell for the traceback kernel.  local: (maximum, first row of its row pair, -);
+    // other modes: (working-space score of the end cell, i, j)
+    if (lane < (int)B.count) {
         BaLocalBest bb;
         bb.score = best_sc;
         bb.i = best_i;
-        bb.j = 0;
+        bb.j = best_j;
         bb.pad = 0;
         P.best[B.first + lane] = bb;
     }
@@ -456,7 +515,6 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     const uint32_t p = live ? P.perm[B.first + lane] : 0u;
     const int n = (int)B.n, m = (int)B.m;
     const int g = P.gap;
-    const int32_t *hb = P.hb + B.hb_off + lane;
     const uint32_t *dir = P.dir + B.dir_off + (size_t)lane * CHW;
     const uint64_t o1 = live ? P.s1_off[p] : 0, o2 = live ? P.s2_off[p] : 0;
     const int cgs = (m + 3) / 4;
@@ -479,47 +537,39 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     int i = 0, j = 0, cur = 0;
     int64_t score = 0;
     if (live) {
-        if (MODE == BA_GLOBAL) {
-            i = n;
-            j = m;
-            cur = hb[(size_t)m * 64];
-            score = (int64_t)cur - (int64_t)g * (n + m);
-        } else if (MODE == BA_LOCAL) {
-            const BaLocalBest bb = P.best[B.first + lane];
+        const BaLocalBest bb = P.best[B.first + lane];
+        if (MODE == BA_LOCAL) {
             score = bb.score;
             if (bb.score > 0) {
-                // first column of row bb.i that reaches the maximum: rebuild the row's
-                // exact scores left to right from their residues (H(i,0) = 0)
-                const int t = bb.i - 1 + front;
-                const int rb = t / F, sh = (t % F) * K;
-                int v = 0;
-                for (int cg = 0; cg < cgs && j == 0; ++cg) {
-                    const uint4 q = block_words(rb, cg);
-                    const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+                // The DP kernel names a pair of rows (bb.i, bb.i+1) that holds the maximum.
+                // First cell in row-major order: rebuild each row's exact scores left to
+                // right from their residues (H(i,0) = 0) until one equals the maximum.
+                for (int row = max(bb.i, 1); row <= min(bb.i + 1, n) && j == 0; ++row) {
+                    const int t = row - 1 + front;
+                    const int rb = t / F, sh = (t % F) * K;
+                    int v = 0;
+                    for (int cg = 0; cg < cgs && j == 0; ++cg) {
+                        const uint4 q = block_words(rb, cg);
+                        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const uint32_t rho = (wd[c] >> sh) & MASK;
-                        v = v + (int)((rho - (uint32_t)v + (uint32_t)off) & MASK) - off;
-                        if (j == 0 && cg * 4 + c < m && v == bb.score) j = cg * 4 + c + 1;
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t rho = (wd[c] >> sh) & MASK;
+                            v = v + (int)((rho - (uint32_t)v + (uint32_t)off) & MASK) - off;
+                            if (j == 0 && cg * 4 + c < m && v == bb.score) j = cg * 4 + c + 1;
+                        }
                     }
+                    i = row;
                 }
-                i = bb.i;
                 cur = bb.score;
             }
         } else {
-            // leftmost strict maximum of the bottom row, scan from column 0 (align_pair.go:169-182)
-            i = n;
-            cur = hb[0];
-            score = (int64_t)cur - (int64_t)g * n;
-            for (int jj = 1; jj <= m; ++jj) {
-                const int hv = hb[(size_t)jj * 64];
-                const int64_t v = (int64_t)hv - (int64_t)g * (n + jj);
-                if (v > score) {
-                    score = v;
-                    j = jj;
-                    cur = hv;
-                }
-            }
+            // end cell found by the DP kernel: (n, m) for global (align.go:123-124), the
+            // leftmost strict maximum of the bottom row for fitting / overlap
+            // (align_pair.go:169-182); bb.score is its working-space score Hs = H + g*(i+j)
+            i = bb.i;
+            j = bb.j;
+            cur = bb.score;
+            score = (int64_t)cur - (int64_t)g * (i + j);
         }
         P.scores[p] = score;
     }
