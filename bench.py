@@ -96,7 +96,7 @@ def main():
         dist = dist_mod
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    from bio_amd import _native, synth
+    from bio_amd import _native, shard, synth
 
     N, L = args.pairs, args.len
     t_gen = time.time()
@@ -154,10 +154,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, device=dev)
     ms_g, n_g = plan_g.dp_ms()
     ms_l, n_l = plan_l.dp_ms()
 
