@@ -4,7 +4,7 @@ ARCH ?= gfx950
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 CSRC := bio_amd/csrc
 LIB := bio_amd/lib/libbioalign.so
-OBJS := build/kernels.o build/api.o
+OBJS := build/kernels.o build/kernels_affine.o build/api.o
 
 all: $(LIB) oracle
 
@@ -12,7 +12,11 @@ $(LIB): $(OBJS)
 	@mkdir -p bio_amd/lib
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
 
-build/kernels.o: $(CSRC)/kernels.hip $(CSRC)/common.h
+build/kernels.o: $(CSRC)/kernels.hip $(CSRC)/common.h $(CSRC)/device_helpers.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+build/kernels_affine.o: $(CSRC)/kernels_affine.hip $(CSRC)/common.h $(CSRC)/device_helpers.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 

@@ -23,6 +23,8 @@ extern "C" size_t ba_dp_linear_lds_bytes(int nb, int nb4, int na_pad, int R, int
 extern "C" hipError_t ba_launch_pack(const BaPackParams &P, hipStream_t st);
 extern "C" hipError_t ba_launch_dp_linear(const BaDpParams &P, int mode, int R, int K, int waves, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_linear(const BaTraceParams &P, int mode, int R, int K, hipStream_t st);
+extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, int waves, hipStream_t st);
+extern "C" hipError_t ba_launch_trace_affine(const BaTraceParams &P, int mode, int R, hipStream_t st);
 
 namespace {
 
@@ -199,9 +201,12 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     pl->gap_symbol = in->gap_symbol;
     pl->na = in->na;
     pl->nb = in->nb;
-    if (pl->affine) return ctx->fail(BIOALIGN_EUNSUPPORTED, "affine gaps are not implemented yet");
-    if (pl->gap < 0)
-        return ctx->fail(BIOALIGN_EUNSUPPORTED, "negative gap penalty %d is outside the fast kernels", pl->gap);
+    if (pl->gap_open < 0 || pl->gap_ext < 0)
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "negative gap penalty (%d, %d) is outside the fast kernels",
+                         pl->gap_open, pl->gap_ext);
+    if (pl->affine && pl->gap_open < pl->gap_ext)
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "gap_open %d < gap_extend %d is outside the fast kernels",
+                         pl->gap_open, pl->gap_ext);
 
     // shapes
     std::vector<uint32_t> len1(N), len2(N);
@@ -224,7 +229,8 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         return ctx->fail(BIOALIGN_EINVAL, "offsets must start at 0");
 
     // int8 profile with the bias folded in (kernels.hip: biased score space)
-    const int bias = (pl->mode == BIOALIGN_LOCAL) ? 0 : 2 * pl->gap;
+    // (affine: every level is biased by ext*(i+j) and the strip keeps H' - (open - ext), kernels_affine.hip)
+    const int bias = pl->affine ? pl->gap_open + pl->gap_ext : (pl->mode == BIOALIGN_LOCAL) ? 0 : 2 * pl->gap;
     int wmax = 0;
     for (int i = 0; i < pl->na * pl->nb; ++i) {
         const int64_t v = (int64_t)in->score_table[i] + bias;
@@ -237,7 +243,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     pl->nb4 = (pl->nb + 3) / 4;
     pl->na_pad = ((pl->na + 1 + 31) / 32) * 32;
     // residue bits: adjacent working-space scores differ by 0 .. max(w)+2g (kernels.hip)
-    {
+    if (!pl->affine) {
         const int64_t span = std::max<int64_t>((int64_t)wmax + 2 * (int64_t)pl->gap, 0) + 1;
         pl->K = span <= 4 ? 2 : span <= 16 ? 4 : span <= 256 ? 8 : 0;
         if (!pl->K)
@@ -245,7 +251,18 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     }
     if ((max_n + max_m + 2) * 128 >= (1ull << 31))
         return ctx->fail(BIOALIGN_EUNSUPPORTED, "pair too long for 32-bit scores on the batch path");
-    (void)min_nm_max;
+    if (pl->affine) {
+        // working-space magnitudes stay far below the kernels' "minus infinity" and floor offsets
+        if ((max_n + max_m + 2) * (uint64_t)(128 + pl->gap_open + pl->gap_ext) >= (1ull << 22))
+            return ctx->fail(BIOALIGN_EUNSUPPORTED, "pair too long for the affine batch kernels");
+        // local: (true score << key_shift) must fit 31 bits (position key, kernels_affine.hip)
+        const int key_shift = bit_length(max_m | 1) + 1;
+        if (pl->mode == BIOALIGN_LOCAL && (min_nm_max + 1) * (uint64_t)std::max(wmax, 1) >= (1ull << (31 - key_shift)))
+            return ctx->fail(BIOALIGN_EUNSUPPORTED, "local affine scores do not fit the position key");
+        if (pl->gap_open > 127)
+            return ctx->fail(BIOALIGN_EUNSUPPORTED, "gap_open %d does not fit the int8 profile", pl->gap_open);
+        pl->K = 0;
+    }
     // strip height and block shape: the strip profile (nb * R bytes per lane) lives in LDS
     pl->R = (pl->nb <= 6 && pl->K <= 4) ? 32 : 16;
     pl->waves = 4;
@@ -255,6 +272,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         return ctx->fail(BIOALIGN_EUNSUPPORTED, "alphabet of %d column symbols needs more LDS than a CU has", pl->nb);
     const int R = pl->R;
     const int chw = 4 * (R * pl->K / 32);  // residue dwords per lane per group of 4 columns
+    const uint64_t cpw = 32 / R;           // affine: columns per decision word
 
     // shape-sort the pairs; identical shapes become bundles of <= 64
     std::vector<uint32_t> perm(N);
@@ -278,7 +296,10 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         const uint64_t strips = (n + R - 1) / R;
         const uint64_t sz_s1w = strips * R / 4 * 64, sz_s2w = (uint64_t)((m + 3) / 4) * 64;
         // boundary deltas: two buffers (strip parity) of ceil(m / F) words per lane, F >= 4
-        const uint64_t sz_hb = 2 * (uint64_t)((m + 3) / 4 + 1) * 64, sz_dir = strips * (uint64_t)((m + 3) / 4) * 64 * chw;
+        // (affine: two buffers of (hq, F') per column and lane; four decision planes per column word)
+        const uint64_t sz_hb = pl->affine ? 2 * (uint64_t)m * 64 * 2 : 2 * (uint64_t)((m + 3) / 4 + 1) * 64;
+        const uint64_t sz_dir = pl->affine ? strips * ((m + cpw - 1) / cpw) * 64 * 4
+                                           : strips * (uint64_t)((m + 3) / 4) * 64 * chw;
         const uint64_t after = (o_s1w + sz_s1w + o_s2w + sz_s2w + o_hb + sz_hb + o_dir + sz_dir) * 4;
         if (after > budget && pl->bundles.size() > chunk_begin) {
             pl->chunks.push_back({chunk_begin, (uint32_t)pl->bundles.size()});
@@ -320,6 +341,19 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
             }
             wt[(size_t)c * pl->na_pad + a] = w;
         }
+    if (pl->affine && (pl->mode == BIOALIGN_LOCAL || pl->mode == BIOALIGN_FITTING)) {
+        // free top row: the rows of the first strip that lie above the matrix reproduce
+        // H'(0, j) = ext*j through their diagonal when the padding code scores `open`
+        // (kernels_affine.hip); other modes keep -128 there
+        for (int c = 0; c < pl->nb4; ++c) {
+            uint32_t w = 0;
+            for (int q = 0; q < 4; ++q) {
+                const int v = 4 * c + q < pl->nb ? pl->gap_open : -128;
+                w |= (uint32_t)(uint8_t)(int8_t)v << (8 * q);
+            }
+            wt[(size_t)c * pl->na_pad + pl->na] = w;
+        }
+    }
 
     // device memory
     HIP_TRY(ctx, hipSetDevice(ctx->devices[pl->device]));
@@ -425,7 +459,10 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         dp.gap_ext = pl->gap_ext;
         const bool timed = pl->ev_used < pl->ev0.size();
         if (timed) HIP_TRY(ctx, hipEventRecord(pl->ev0[pl->ev_used], st));
-        HIP_TRY(ctx, ba_launch_dp_linear(dp, pl->mode, pl->R, pl->K, pl->waves, st));
+        if (pl->affine)
+            HIP_TRY(ctx, ba_launch_dp_affine(dp, pl->mode, pl->R, pl->waves, st));
+        else
+            HIP_TRY(ctx, ba_launch_dp_linear(dp, pl->mode, pl->R, pl->K, pl->waves, st));
         if (timed) {
             HIP_TRY(ctx, hipEventRecord(pl->ev1[pl->ev_used], st));
             ++pl->ev_used;
@@ -462,7 +499,10 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         tr.t2 = d_t2;
         tr.t_off = d_t_off;
         tr.t_len = d_t_len;
-        HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, st));
+        if (pl->affine)
+            HIP_TRY(ctx, ba_launch_trace_affine(tr, pl->mode, pl->R, st));
+        else
+            HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, st));
     }
     pl->ran = true;
     return 0;

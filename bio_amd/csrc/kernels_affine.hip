@@ -1,0 +1,513 @@
+// kernels_affine.hip -- gfx950 kernels of the batched pairwise aligner, affine gaps
+// (three-level Gotoh), four modes.
+//
+// Recurrences (reference align_affine.go:44-103, evaluated in integers; borders and end
+// cells of the four modes follow align_pair.go:109-195 on the middle level, as the
+// oracle's bo_align_affine restates them):
+//   E(i,j) = max(E(i,j-1) - ext, H(i,j-1) - open)      gap in s1, extension wins ties (51-57)
+//   F(i,j) = max(F(i-1,j) - ext, H(i-1,j) - open)      gap in s2, extension wins ties (67-75)
+//   H(i,j) = first maximum of [0 (local only)], F, H(i-1,j-1) + w, E      strict '>' (82-100)
+// so a gap of length L costs open + (L-1)*ext.
+//
+// Working score space.  Every level runs biased by ext*(i+j): X' = X + ext*(i+j).  Both
+// extension moves then cost nothing, opening costs c = open - ext and the diagonal costs
+// w + 2*ext:
+//   E' = max(E'(left), H'(left) - c)     F' = max(F'(up), H'(up) - c)
+//   H' = max3(E', F', H'(diag) + w + 2*ext)
+// All candidates of one decision carry the same bias, so every comparison -- and every
+// back-pointer -- is the reference's.  A strip keeps hq = H' - c and E' per row in VGPRs
+// (the profile byte holds w + 2*ext + c so that the diagonal add works on hq directly).
+// The true zero of local mode is ext*(i+j) in this space: wave-uniform, an SGPR operand.
+//
+// Traceback matrix: four decision bits per cell, each the sign bit of one subtraction,
+// shifted into a bit plane with one v_alignbit_b32:
+//   nF = [F' != H']   nD = [diag + w != H']   oE = [E' opened from H]   oF = [F' opened from H]
+// Middle-level back-pointer = G2 (close the gap in s2) if !nF, else diagonal if !nD, else
+// G1 -- exactly the candidate order above.  (Local: a cell whose true score is 0 is a
+// skip-prefix cell whatever its bits say; the traceback tracks the true score.)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "device_helpers.h"
+
+#define BA_NEG (-(1 << 28))  // minus infinity of the E / F levels (align_affine.go:36-37, 45-46, 63-64)
+
+// push the sign bit of t into the bottom of a bit plane
+__device__ __forceinline__ uint32_t ba_push_sign(uint32_t acc, int t)
+{
+    return __builtin_amdgcn_alignbit(acc, (uint32_t)t, 31);
+}
+
+// One column of one strip.  `top_hq`/`f` enter as hq and F' of the row above the strip.
+// Local mode clamps H' from below at its zero level ext*(i+j) -- wave-uniform, kept as a
+// running scalar (fl) -- and folds the best-cell search into one v_lshl_add + half a v_max3
+// per cell:  key = (true score << key_shift) | (first row of its pair ? 1 : 0) << jbits | (jmax - j),
+// so the largest key of a row pair is its best cell, first in row-major order.
+template <int MODE, int R>
+__device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint32_t (&acc)[4], int (&rkey)[R / 2],
+                                                 const uint32_t (&pw)[R / 4], int top_hq, int &f, int &topdiag, int c,
+                                                 int ge, int fl, int key_shift, int ks, int kstep, int pbit)
+{
+    int up = top_hq, diag = topdiag;
+    topdiag = top_hq;
+    int kprev = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int eo = e[r];
+        const int en = max(eo, hq[r]);
+        acc[2] = ba_push_sign(acc[2], eo - en);
+        const int fn = max(f, up);
+        acc[3] = ba_push_sign(acc[3], f - fn);
+        const int d = diag + ba_sbyte(pw[r >> 2], r & 3);
+        int H = ba_max3(en, fn, d);
+        if (MODE == BA_LOCAL) {
+            fl += ge;      // zero level of row r: ext*(i+j)
+            ks -= kstep;   // (jmax - j) - (zero level << key_shift)
+            H = max(H, fl);
+        }
+        acc[0] = ba_push_sign(acc[0], fn - H);
+        acc[1] = ba_push_sign(acc[1], d - H);
+        if (MODE == BA_LOCAL) {
+            const int key = (int)(((uint32_t)H << key_shift) + (uint32_t)(ks + ((r & 1) ? 0 : pbit)));
+            if (r & 1)
+                rkey[r / 2] = ba_max3(rkey[r / 2], kprev, key);
+            else
+                kprev = key;
+        }
+        const int hn = H - c;
+        diag = hq[r];
+        hq[r] = hn;
+        e[r] = en;
+        f = fn;
+        up = hn;
+    }
+}
+
+// Layout of the decision words of one bundle (dwords):
+//   [strip][column word cw = (j-1) / CPW][lane][plane 0..3]       CPW = 32 / R columns per word
+// bit 31 - ((j-1) % CPW * R + r) of a word belongs to row r of the strip.  The four planes
+// of one (strip, column word, lane) are one aligned uint4.
+template <int MODE, int R>
+__global__ void __launch_bounds__(256) ba_dp_affine_kernel(BaDpParams P)
+{
+    extern __shared__ __align__(16) uint32_t lds[];
+    constexpr int HALVES = R / 16;
+    constexpr int CPW = 32 / R;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves = blockDim.x >> 6;
+
+    const int wt_words = P.nb4 * P.na_pad;
+    const int wt_aligned = (wt_words + 3) & ~3;
+    for (int i = threadIdx.x; i < wt_words; i += blockDim.x) lds[i] = P.wt[i];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x)
+        lds[wt_aligned + i] = i < 64 ? reinterpret_cast<const uint32_t *>(P.code1)[i]
+                                     : reinterpret_cast<const uint32_t *>(P.code2)[i - 64];
+    const uint8_t *code1 = reinterpret_cast<const uint8_t *>(lds + wt_aligned);
+    const uint8_t *code2 = code1 + 256;
+    __syncthreads();
+
+    const uint32_t b_idx = P.bundle_begin + blockIdx.x * waves + wave;
+    if (b_idx >= P.bundle_end) return;
+    const BaBundle B = P.bundles[b_idx];
+    const int n = (int)B.n, m = (int)B.m;
+    const int ge = P.gap_ext, c = P.gap_open - P.gap_ext;
+    const int strips = (n + R - 1) / R;
+    const int cgs = (m + 3) / 4;
+    const int cws = (m + CPW - 1) / CPW;
+    const int front = strips * R - n;
+    constexpr bool top_free = (MODE == BA_LOCAL || MODE == BA_FITTING);
+    constexpr bool left_free = (MODE == BA_LOCAL || MODE == BA_OVERLAP);
+
+    uint8_t *prof = reinterpret_cast<uint8_t *>(lds + wt_aligned + 128) + (size_t)wave * P.nb * (HALVES * 64 * 16);
+    uint8_t *prof_lane = prof + lane * 16;
+
+    // the row a strip hands to the next one: (hq, F') per column, two buffers by strip parity
+    int2 *bnd = reinterpret_cast<int2 *>(P.hb + B.hb_off) + lane;
+    uint4 *dir = reinterpret_cast<uint4 *>(P.dir + B.dir_off) + lane;
+    const uint32_t *s1w = P.s1w + B.s1w_off + lane;
+    const uint32_t *s2w = P.s2w + B.s2w_off + lane;
+
+    // local: position key (see ba_affine_column); jbits covers 1..m
+    const int jbits = 32 - __builtin_clz((uint32_t)(m | 1));
+    const int key_shift = jbits + 1;
+    const int jmax = (1 << jbits) - 1;
+
+    // H'(i, 0) and H'(0, j): align_pair.go:110-113, 130-131, 158-159, 187-188 on the middle level
+    auto col0 = [&](int i) { return left_free ? ge * max(i, 0) : (i >= 1 ? -c : 0); };
+    auto row0 = [&](int j) { return top_free ? ge * j : (j >= 1 ? -c : 0); };
+
+    int best_sc = 0, best_i = 0, best_j = 0;
+    if (MODE == BA_GLOBAL) {  // strips == 0: the end cell is (0, m) on the top border
+        best_j = m;
+        best_sc = m >= 1 ? -P.gap_open - (m - 1) * ge : 0;
+    }
+
+    for (int s = 0; s < strips; ++s) {
+        const int i0 = n - (strips - s) * R;
+        const bool last_strip = (s == strips - 1);
+        const int2 *bnd_rd = bnd + (size_t)((s + 1) & 1) * m * 64;
+        int2 *bnd_wr = bnd + (size_t)(s & 1) * m * 64;
+        uint32_t aw[R / 4];
+#pragma unroll
+        for (int q = 0; q < R / 4; ++q) aw[q] = s1w[(size_t)(s * (R / 4) + q) * 64];
+        ba_build_strip_profile<R>(lds, P.nb, P.nb4, P.na_pad, code1, P.pad_code, aw, s, front, prof_lane);
+
+        int hq[R], e[R], rkey[R / 2];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            hq[r] = col0(i0 + r + 1) - c;
+            e[r] = BA_NEG;  // align_affine.go:45-46
+            rkey[r / 2] = 0;
+        }
+        int topdiag = col0(i0) - c;
+        uint4 *dirs = dir + (size_t)s * cws * 64;
+        uint32_t acc[4] = {0, 0, 0, 0};
+        // fitting / overlap hand the last strip's bottom row over as well: the end-cell scan reads it back
+        const bool write_bnd = !last_strip || MODE == BA_FITTING || MODE == BA_OVERLAP;
+
+        struct GroupIn {
+            uint32_t sw;
+            int2 b[4];
+        };
+        auto fetch_group = [&](int cg) {
+            GroupIn gi;
+            gi.sw = s2w[(size_t)cg * 64];
+            if (s > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gi.b[q] = bnd_rd[(size_t)min(cg * 4 + q, m - 1) * 64];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gi.b[q] = make_int2(0, 0);
+            }
+            return gi;
+        };
+        auto column_group = [&](int cg, const GroupIn &in, auto full) {
+            constexpr bool FULL = decltype(full)::value;
+            const int jbase = cg * 4 + 1;
+            uint32_t bcode[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bcode[q] = code2[(in.sw >> (q * 8)) & 0xffu];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (FULL || jbase + q <= m) {
+                    const int j = jbase + q;
+                    const uint4 *pp = reinterpret_cast<const uint4 *>(prof_lane + (size_t)bcode[q] * (HALVES * 64 * 16));
+                    uint32_t pw[R / 4];
+#pragma unroll
+                    for (int hf = 0; hf < HALVES; ++hf) {
+                        const uint4 v = pp[hf * 64];
+                        pw[hf * 4 + 0] = v.x;
+                        pw[hf * 4 + 1] = v.y;
+                        pw[hf * 4 + 2] = v.z;
+                        pw[hf * 4 + 3] = v.w;
+                    }
+                    // the row above the strip: row 0 (F = -inf, align_affine.go:63-64) or the previous strip's last row
+                    const int top_hq = (s == 0) ? row0(j) - c : in.b[q].x;
+                    int f = (s == 0) ? BA_NEG : in.b[q].y;
+                    const int fl0 = ge * (i0 + j);  // local: zero level of the row above the strip
+                    ba_affine_column<MODE, R>(hq, e, acc, rkey, pw, top_hq, f, topdiag, c, ge, fl0, key_shift,
+                                              (jmax - j) - (fl0 << key_shift), ge << key_shift, 1 << jbits);
+                    if ((j - 1) % CPW == CPW - 1)
+                        dirs[(size_t)((j - 1) / CPW) * 64] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                    if (write_bnd) bnd_wr[(size_t)(j - 1) * 64] = make_int2(hq[R - 1], f);
+                }
+            }
+        };
+        const int full_groups = m / 4;
+        if (cgs > 0) {
+            GroupIn nxt = fetch_group(0);
+            for (int cg = 0; cg < full_groups; ++cg) {
+                const GroupIn cur = nxt;
+                nxt = fetch_group(min(cg + 1, cgs - 1));
+                column_group(cg, cur, std::true_type{});
+            }
+            if (full_groups < cgs) column_group(full_groups, nxt, std::false_type{});
+            // a half-filled last word (R == 16, odd m): its column sits in the top half like any first column
+            if (CPW == 2 && (m & 1))
+                dirs[(size_t)(m / 2) * 64] = make_uint4(acc[0] << 16, acc[1] << 16, acc[2] << 16, acc[3] << 16);
+        }
+
+        if (last_strip && MODE != BA_LOCAL) {
+            int ej = m, ecur = hq[R - 1];  // global: the last cell (align_pair.go:123-126)
+            if (MODE == BA_FITTING || MODE == BA_OVERLAP) {
+                // bottom row: leftmost strict maximum of the true scores, scan from column 0
+                // (align_pair.go:169-182); true score = H'(n, j) - ext*j up to a constant
+                ecur = col0(n) - c;
+                ej = 0;
+                int ev = ecur;
+                for (int j = 1; j <= m; ++j) {
+                    const int hv = bnd_wr[(size_t)(j - 1) * 64].x;
+                    const int v = hv - ge * j;
+                    if (v > ev) {
+                        ev = v;
+                        ej = j;
+                        ecur = hv;
+                    }
+                }
+            }
+            // true score of the end cell: H = hq + c - ext*(i+j)
+            best_sc = ecur + c - ge * (n + ej);
+            best_i = n;
+            best_j = ej;
+        }
+        if (MODE == BA_LOCAL) {
+            // first strict maximum in row-major order (align.go:216-221 on the middle level).
+            // Row pairs that lie wholly above the matrix (first strip) carry no scores.
+#pragma unroll
+            for (int r = 0; r < R; r += 2) {
+                const int k = rkey[r / 2];
+                const int sc = k >> key_shift;
+                if (i0 + r + 2 >= 1 && sc > best_sc) {
+                    best_sc = sc;
+                    best_i = i0 + r + 1 + (((k >> jbits) & 1) ? 0 : 1);
+                    best_j = jmax - (k & jmax);
+                }
+            }
+        }
+    }
+    if (lane < (int)B.count) {
+        BaLocalBest bb;
+        bb.score = best_sc;  // true score of the end cell
+        bb.i = best_i;
+        bb.j = best_j;
+        bb.pad = 0;
+        P.best[B.first + lane] = bb;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// traceback, affine: one lane walks one pair's path over (level, node) exactly as the
+// oracle's canonical traceback does, reading the decision bits, and writes both traces
+// back to front into the pair's output slot.
+// ----------------------------------------------------------------------------
+template <int MODE, int R>
+__global__ void __launch_bounds__(256) ba_trace_affine_kernel(BaTraceParams P)
+{
+    extern __shared__ __align__(16) uint32_t lds[];
+    constexpr int CPW = 32 / R;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int tbl_words = (P.na * P.nb + 3) & ~3;
+    int32_t *tbl = reinterpret_cast<int32_t *>(lds);
+    uint8_t *code1 = reinterpret_cast<uint8_t *>(lds + tbl_words);
+    uint8_t *code2 = code1 + 256;
+    for (int i = threadIdx.x; i < P.na * P.nb; i += blockDim.x) tbl[i] = P.table[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        code1[i] = P.code1[i];
+        code2[i] = P.code2[i];
+    }
+    __syncthreads();
+    const uint32_t b_idx = P.bundle_begin + blockIdx.x * waves + wave;
+    if (b_idx >= P.bundle_end) return;
+    const BaBundle B = P.bundles[b_idx];
+    const bool live = lane < (int)B.count;
+    const uint32_t p = live ? P.perm[B.first + lane] : 0u;
+    const int n = (int)B.n, m = (int)B.m;
+    const int go = P.gap_open, ge = P.gap_ext;
+    const uint4 *dir = reinterpret_cast<const uint4 *>(P.dir + B.dir_off) + lane;
+    const uint64_t o1 = live ? P.s1_off[p] : 0, o2 = live ? P.s2_off[p] : 0;
+    const int cws = (m + CPW - 1) / CPW;
+    const int front = ((n + R - 1) / R) * R - n;
+    constexpr bool top_free = (MODE == BA_LOCAL || MODE == BA_FITTING);
+    constexpr bool left_free = (MODE == BA_LOCAL || MODE == BA_OVERLAP);
+
+    int i = 0, j = 0, V = 0;
+    if (live) {
+        const BaLocalBest bb = P.best[B.first + lane];
+        i = bb.i;
+        j = bb.j;
+        V = bb.score;
+        P.scores[p] = (int64_t)bb.score;
+    }
+    if (P.score_only) return;
+
+    const uint64_t slot = o1 + o2;
+    const uint64_t cap = (uint64_t)n + (uint64_t)m;
+    const uint32_t *s1w = P.s1w + B.s1w_off + lane;
+    const uint32_t *s2w = P.s2w + B.s2w_off + lane;
+    int k1_tag = -1, k2_tag = -1;
+    uint32_t x_word = 0, y_word = 0;
+    auto sym1 = [&](int i1) {  // s1[i1-1]
+        const int t = i1 - 1 + front;
+        if ((t >> 2) != k1_tag) {
+            k1_tag = t >> 2;
+            x_word = s1w[(size_t)k1_tag * 64];
+            asm volatile("" : "+v"(x_word));
+        }
+        return (x_word >> ((t & 3) * 8)) & 0xffu;
+    };
+    auto sym2 = [&](int j1) {  // s2[j1-1]
+        const int cc = j1 - 1;
+        if ((cc >> 2) != k2_tag) {
+            k2_tag = cc >> 2;
+            y_word = s2w[(size_t)k2_tag * 64];
+            asm volatile("" : "+v"(y_word));
+        }
+        return (y_word >> ((cc & 3) * 8)) & 0xffu;
+    };
+    BaBackWriter w1, w2;
+    w1.init(P.t1, slot + cap);
+    w2.init(P.t2, slot + cap);
+    const uint32_t gs = P.gap_symbol;
+
+    // the decision word of (strip, column word) last fetched by this lane
+    int tag = -1;
+    uint4 q = make_uint4(0, 0, 0, 0);
+    uint32_t sh = 0;
+    auto fetch = [&](int ii, int jj) {  // 1 <= ii <= n, 1 <= jj <= m
+        const int t = ii - 1 + front;
+        const int s = t / R, r = t % R;
+        const int cw = (jj - 1) / CPW;
+        const int id = s * cws + cw;
+        if (id != tag) {
+            tag = id;
+            q = dir[(size_t)id * 64];
+            asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));
+        }
+        sh = 31u - (uint32_t)(((jj - 1) % CPW) * R + r);
+    };
+
+    enum { LV_MM = 0, LV_G1 = 1, LV_G2 = 2 };
+    int level = LV_MM;
+    bool done = !live || (i == 0 && j == 0);
+    while (__any(!done)) {
+        if (!done) {
+            if (level == LV_MM) {
+                // back-pointer of the middle level (oracle: bmm)
+                if (i == 0) {
+                    if (top_free || j == 0) done = true; else level = LV_G1;   // top border: sg2 = -inf, no diagonal
+                } else if (j == 0) {
+                    if (left_free) done = true; else level = LV_G2;            // left border
+                } else if (MODE == BA_LOCAL && V == 0) {
+                    done = true;                                               // skip-prefix cell
+                } else {
+                    fetch(i, j);
+                    if (((q.x >> sh) & 1u) == 0) {
+                        level = LV_G2;
+                    } else if (((q.y >> sh) & 1u) == 0) {
+                        const uint32_t x = sym1(i), y = sym2(j);
+                        w1.put(x);
+                        w2.put(y);
+                        if (MODE == BA_LOCAL) V -= tbl[(int)code1[x] * P.nb + (int)code2[y]];
+                        --i;
+                        --j;
+                    } else {
+                        level = LV_G1;
+                    }
+                }
+            }
+            if (!done && level == LV_G1) {
+                // gap in s1: emit (gap, s2[j-1]); j >= 1 on this level
+                bool opened;
+                if (i == 0) {
+                    opened = (j == 1);  // top border (open >= ext): only the first step opens
+                } else if (j == 1) {
+                    opened = true;      // E(i, 0) = -inf
+                } else {
+                    fetch(i, j);
+                    opened = ((q.z >> sh) & 1u) != 0;
+                }
+                w1.put(gs);
+                w2.put(sym2(j));
+                if (MODE == BA_LOCAL) V += opened ? go : ge;
+                level = opened ? LV_MM : LV_G1;
+                --j;
+            } else if (!done && level == LV_G2) {
+                // gap in s2: emit (s1[i-1], gap); i >= 1 on this level
+                bool opened;
+                if (j == 0) {
+                    opened = (i == 1);
+                } else if (i == 1) {
+                    opened = true;      // F(0, j) = -inf
+                } else {
+                    fetch(i, j);
+                    opened = ((q.w >> sh) & 1u) != 0;
+                }
+                w1.put(sym1(i));
+                w2.put(gs);
+                if (MODE == BA_LOCAL) V += opened ? go : ge;
+                level = opened ? LV_MM : LV_G2;
+                --i;
+            }
+            if (level == LV_MM && i == 0 && j == 0) done = true;
+        }
+    }
+    if (live) {
+        w1.finish();
+        w2.finish();
+        const uint64_t len = (uint64_t)w1.length();
+        P.t_off[p] = slot + cap - len;
+        P.t_len[p] = len;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// host-side launchers (called from api.cpp)
+// ----------------------------------------------------------------------------
+extern "C" size_t ba_dp_linear_lds_bytes(int nb, int nb4, int na_pad, int R, int waves);
+
+template <int MODE, int R>
+static hipError_t launch_dp_aff(const BaDpParams &P, int waves, hipStream_t st)
+{
+    const uint32_t nbundles = P.bundle_end - P.bundle_begin;
+    const uint32_t blocks = (nbundles + waves - 1) / waves;
+    const size_t lds = ba_dp_linear_lds_bytes(P.nb, P.nb4, P.na_pad, R, waves);
+    hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R>), dim3(blocks), dim3(waves * 64), lds, st, P);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_dp_aff_mode(const BaDpParams &P, int R, int waves, hipStream_t st)
+{
+    if (R == 32) return launch_dp_aff<MODE, 32>(P, waves, st);
+    if (R == 16) return launch_dp_aff<MODE, 16>(P, waves, st);
+    return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, int waves, hipStream_t st)
+{
+    if (P.bundle_end == P.bundle_begin) return hipSuccess;
+    switch (mode) {
+    case BA_GLOBAL: return launch_dp_aff_mode<BA_GLOBAL>(P, R, waves, st);
+    case BA_LOCAL: return launch_dp_aff_mode<BA_LOCAL>(P, R, waves, st);
+    case BA_FITTING: return launch_dp_aff_mode<BA_FITTING>(P, R, waves, st);
+    case BA_OVERLAP: return launch_dp_aff_mode<BA_OVERLAP>(P, R, waves, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int MODE, int R>
+static hipError_t launch_trace_aff(const BaTraceParams &P, hipStream_t st)
+{
+    const int waves = 4;
+    const uint32_t nbundles = P.bundle_end - P.bundle_begin;
+    const uint32_t blocks = (nbundles + waves - 1) / waves;
+    const size_t lds = ((size_t)((P.na * P.nb + 3) & ~3) + 128) * 4;
+    hipLaunchKernelGGL((ba_trace_affine_kernel<MODE, R>), dim3(blocks), dim3(waves * 64), lds, st, P);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_trace_aff_mode(const BaTraceParams &P, int R, hipStream_t st)
+{
+    if (R == 32) return launch_trace_aff<MODE, 32>(P, st);
+    if (R == 16) return launch_trace_aff<MODE, 16>(P, st);
+    return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t ba_launch_trace_affine(const BaTraceParams &P, int mode, int R, hipStream_t st)
+{
+    if (P.bundle_end == P.bundle_begin) return hipSuccess;
+    switch (mode) {
+    case BA_GLOBAL: return launch_trace_aff_mode<BA_GLOBAL>(P, R, st);
+    case BA_LOCAL: return launch_trace_aff_mode<BA_LOCAL>(P, R, st);
+    case BA_FITTING: return launch_trace_aff_mode<BA_FITTING>(P, R, st);
+    case BA_OVERLAP: return launch_trace_aff_mode<BA_OVERLAP>(P, R, st);
+    }
+    return hipErrorInvalidValue;
+}

@@ -1,0 +1,149 @@
+"""GPU parity, affine gaps: the HIP Gotoh kernels through the C ABI against the
+oracle's integer Gotoh (bo_align_affine), bit for bit on scores and both traces, in all four modes.
+
+What is pinned by the reference: the global SCORE (align_affine.go:36-104,139-140; checked here
+against the oracle's float64 restatement of exactly those lines).  Affine traces and the local /
+fitting / overlap affine variants do not exist in the reference: they are the oracle's canonical
+definition (PARITY UNPINNED beyond the global score), and every trace is also checked
+for self-consistency: it spells the aligned substrings and rescoring it gives the reported score.
+"""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import bio_amd
+from bio_amd import synth
+from oracle import oracle as O
+
+MODES = ("global", "local", "fitting", "overlap")
+
+
+def _seqs(s, o, n):
+    return [bytes(s[int(o[p]):int(o[p + 1])]) for p in range(n)]
+
+
+def _self_consistent(mode, x, y, sc, t1, t2, oa, go, ge):
+    if t1 is None:
+        assert t2 is None
+        return
+    assert len(t1) == len(t2)
+    g = ord("-")
+    a = bytes(b for b in t1 if b != g)
+    b = bytes(b for b in t2 if b != g)
+    assert a in x and b in y
+    if mode == "global":
+        assert a == x and b == y
+    if mode == "fitting":
+        assert a == x
+    if mode == "overlap":
+        assert x.endswith(a) and y.startswith(b)
+    assert O.AffineGap(t1, t2, oa, go, ge) == sc
+
+
+def _check_affine(mode, s1s, s2s, pa, oa, go, ge):
+    scores, t1s, t2s = bio_amd.AlignAffineBatch(mode, s1s, s2s, pa, go, ge)
+    for p, (x, y) in enumerate(zip(s1s, s2s)):
+        want = O.AlignAffine(mode, x, y, oa, go, ge)
+        got = (scores[p], t1s[p], t2s[p])
+        assert got == want, (mode, p, x, y, go, ge, got, want)
+        _self_consistent(mode, x, y, *got, oa, go, ge)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_affine_dna_uniform(mode):
+    # config-4 scoring (+1/-1, open 5, extend 1) on 150 x 150: five strips of 32 rows, 10 rows above the matrix
+    s1, o1, s2, o2 = synth.dna_pairs(200, 150, 150, config=2)
+    _check_affine(mode, _seqs(s1, o1, 200), _seqs(s2, o2, 200), bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1), 5, 1)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_affine_dna_ragged_with_empties(mode):
+    rng = random.Random(77 + MODES.index(mode))
+    alpha = b"ACGT"
+    s1s, s2s = [], []
+    for _ in range(260):
+        n = rng.choice([0, 1, 2, 3, 31, 32, 33, 63, 64, 65, rng.randrange(0, 90)])
+        m = rng.choice([0, 1, 2, 5, 17, rng.randrange(0, 90)])
+        s1s.append(bytes(rng.choice(alpha) for _ in range(n)))
+        s2s.append(bytes(rng.choice(alpha) for _ in range(m)))
+    go, ge = rng.choice([(5, 1), (3, 2), (4, 0), (2, 1)])
+    _check_affine(mode, s1s, s2s, bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1), go, ge)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_affine_low_complexity_ties(mode):
+    # two-letter, highly repetitive inputs: many ties between opening and extending, between levels
+    rng = random.Random(5)
+    s1s = [bytes(rng.choice(b"AAAC") for _ in range(rng.randrange(1, 70))) for _ in range(192)]
+    s2s = [bytes(rng.choice(b"AAAC") for _ in range(rng.randrange(1, 70))) for _ in range(192)]
+    _check_affine(mode, s1s, s2s, bio_amd.MatchAligner(2, -1), O.MatchAligner(2, -1), 3, 1)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_affine_protein(mode):
+    # config-3 scoring: Blosum62, open 11, extend 1 (16-row strips, two columns per decision word)
+    rng = random.Random(11)
+    s1, o1, s2, o2 = synth.protein_pairs(128, 75, 81, config=3)
+    s1s, s2s = _seqs(s1, o1, 128), _seqs(s2, o2, 128)
+    alpha = b"ARNDCQEGHILKMFPSTWYV"
+    for _ in range(60):
+        s1s.append(bytes(rng.choice(alpha) for _ in range(rng.randrange(0, 50))))
+        s2s.append(bytes(rng.choice(alpha) for _ in range(rng.randrange(0, 50))))
+    _check_affine(mode, s1s, s2s, bio_amd.Blosum62, O.Blosum62(), 11, 1)
+
+
+def test_affine_fitting_reads_against_windows():
+    # config-4 shape scaled down: read = s1, window = s2
+    s1, o1, s2, o2 = synth.fitting_reads(70, 60, 400, config=4)
+    s1s, s2s = _seqs(s1, o1, 70), _seqs(s2, o2, 70)
+    for mode in ("fitting", "overlap"):
+        _check_affine(mode, s1s, s2s, bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1), 5, 1)
+
+
+def test_align_global_affine_score_is_the_references():
+    # the one thing the reference pins: smm[last] of align_affine.go:36-104 in float64
+    rng = random.Random(2)
+    alpha = b"ARNDCQEGHILKMFPSTWYV"
+    for _ in range(40):
+        x = bytes(rng.choice(alpha) for _ in range(rng.randrange(1, 40)))
+        y = bytes(rng.choice(alpha) for _ in range(rng.randrange(1, 40)))
+        go, ge = rng.choice([(11.0, 1.0), (5.0, 2.0), (7.0, 0.0)])
+        sc, t1, t2 = bio_amd.AlignGlobalAffine(x, y, bio_amd.Blosum62, go, ge)
+        assert isinstance(sc, float)
+        assert sc == O.AffineGlobalScoreF64(x, y, O.Blosum62(), go, ge)
+        assert bytes(b for b in t1 if b != ord("-")) == x and bytes(b for b in t2 if b != ord("-")) == y
+    # the input on which the reference's own traceback goes wrong: score as written, trace correct
+    sc, t1, t2 = bio_amd.AlignGlobalAffine(b"ACDDE", b"ACE", bio_amd.Blosum62, 5, 1)
+    assert sc == O.AffineGlobalScoreF64(b"ACDDE", b"ACE", O.Blosum62(), 5.0, 1.0)
+    assert t1 == b"ACDDE" and t2.replace(b"-", b"") == b"ACE"
+
+
+def test_affine_unsupported_parameters_fail_loudly():
+    a = bio_amd.MatchAligner(1, -1)
+    with pytest.raises(bio_amd._native.BioAlignError) as e:
+        bio_amd.AlignAffineBatch("global", [b"ACGT"], [b"ACG"], a, 1, 3)  # open < extend
+    assert e.value.code == bio_amd._native.EUNSUPPORTED
+    with pytest.raises(bio_amd._native.BioAlignError):
+        bio_amd.AlignAffineBatch("global", [b"ACGT"], [b"ACG"], a, -1, -2)
+
+
+def test_affine_score_only_and_gap_symbol():
+    a, oa = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
+    s1, o1, s2, o2 = synth.dna_pairs(64, 90, 100, config=7)
+    s1s, s2s = _seqs(s1, o1, 64), _seqs(s2, o2, 64)
+    sc, t1, t2 = bio_amd.AlignAffineBatch("local", s1s, s2s, a, 4, 1, score_only=True)
+    assert t1 is None and t2 is None
+    assert sc == [O.AlignAffine("local", x, y, oa, 4, 1)[0] for x, y in zip(s1s, s2s)]
+    bio_amd.GapSymbol = ord(".")
+    O.set_gap_symbol(ord("."))
+    try:
+        got = bio_amd.AlignAffineBatch("global", [b"ACGTTTTTACGT"], [b"ACGTACGT"], a, 3, 1)
+        want = O.AlignAffine("global", b"ACGTTTTTACGT", b"ACGTACGT", oa, 3, 1)
+        assert (got[0][0], got[1][0], got[2][0]) == want
+        assert want[0] == 8 - 3 - 3 and b"-" not in want[2] and want[2].count(b".") == 4
+    finally:
+        bio_amd.GapSymbol = ord("-")
+        O.set_gap_symbol(ord("-"))
