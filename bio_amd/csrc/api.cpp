@@ -23,7 +23,8 @@ extern "C" size_t ba_dp_linear_lds_bytes(int nb, int nb4, int na_pad, int R, int
 extern "C" hipError_t ba_launch_pack(const BaPackParams &P, hipStream_t st);
 extern "C" hipError_t ba_launch_dp_linear(const BaDpParams &P, int mode, int R, int K, int waves, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_linear(const BaTraceParams &P, int mode, int R, int K, hipStream_t st);
-extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, int waves, hipStream_t st);
+extern "C" size_t ba_dp_affine_lds_bytes(int nb, int nb4, int na_pad, int R, int waves);
+extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, int waves, int pipe, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_affine(const BaTraceParams &P, int mode, int R, hipStream_t st);
 
 namespace {
@@ -77,6 +78,7 @@ struct bioalign_plan {
     uint8_t gap_symbol = '-';
     int na = 0, nb = 0, nb4 = 0, na_pad = 0;
     int R = 32, waves = 4;
+    int pipe = 0;  // affine: one block per bundle, strips pipelined over its waves (kernels_affine.hip)
     int K = 2;  // residue bits per cell in the traceback matrix
     uint64_t cells = 0;
     std::vector<BaBundle> bundles;
@@ -369,6 +371,26 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     if ((rc = dev_alloc(pl, (void **)&pl->d_hb, m_hb * 4))) return rc;
     if ((rc = dev_alloc(pl, (void **)&pl->d_dir, m_dir * 4))) return rc;
     if ((rc = dev_alloc(pl, (void **)&pl->d_best, (N ? N : 1) * sizeof(BaLocalBest)))) return rc;
+    if (pl->affine) {
+        // Few bundles cannot fill 1024 SIMDs with one wavefront each: run the strips of a bundle
+        // as a pipeline over the waves of a block instead (as many waves as strips, up to 8).
+        const int strips_max = (int)((max_n + R - 1) / R);
+        const uint64_t pipe_below = env_u64("BIOALIGN_PIPE_BELOW", 6144);
+        pl->pipe = strips_max >= 2 && pl->bundles.size() < pipe_below;
+        if (pl->pipe) {
+            pl->waves = std::min(8, std::max(2, strips_max));
+            while (pl->waves > 2 && ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, pl->waves) > 80 * 1024)
+                --pl->waves;
+            if ((max_m + 3) / 4 >= 65536) pl->pipe = 0;  // progress word: 16 bits of column groups
+        }
+        if (!pl->pipe) {
+            pl->waves = 4;
+            while (pl->waves > 1 && ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, pl->waves) > 40 * 1024)
+                pl->waves >>= 1;
+        }
+        if (ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, pl->waves) > 160 * 1024)
+            return ctx->fail(BIOALIGN_EUNSUPPORTED, "alphabet of %d column symbols needs more LDS than a CU has", pl->nb);
+    }
     if (!pl->bundles.empty())
         HIP_TRY(ctx, hipMemcpy(pl->d_bundles, pl->bundles.data(), pl->bundles.size() * sizeof(BaBundle),
                                hipMemcpyHostToDevice));
@@ -460,7 +482,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         const bool timed = pl->ev_used < pl->ev0.size();
         if (timed) HIP_TRY(ctx, hipEventRecord(pl->ev0[pl->ev_used], st));
         if (pl->affine)
-            HIP_TRY(ctx, ba_launch_dp_affine(dp, pl->mode, pl->R, pl->waves, st));
+            HIP_TRY(ctx, ba_launch_dp_affine(dp, pl->mode, pl->R, pl->waves, pl->pipe, st));
         else
             HIP_TRY(ctx, ba_launch_dp_linear(dp, pl->mode, pl->R, pl->K, pl->waves, st));
         if (timed) {

@@ -83,3 +83,33 @@ struct BaTraceParams {
     uint8_t *t1, *t2;
     uint64_t *t_off, *t_len;
 };
+
+// ----------------------------------------------------------------------------
+// long mode: ONE pair, rows spread over the lanes of a wavefront (kernels_long.hip)
+//   strip   : 64*T consecutive rows, T per lane; one wavefront sweeps it over all columns,
+//             lane l working on column t - l at step t (anti-diagonal skew)
+//   step    : one column per lane; residue words are stored by step, not by column
+// ----------------------------------------------------------------------------
+struct BaLongParams {
+    const uint8_t *s1, *s2;        // the pair's raw bytes (device)
+    uint32_t n, m;
+    uint32_t strips;               // ceil(n / (64*T)), bottom aligned
+    uint32_t words_per_strip;      // residue dwords per lane per strip = ceil((m + 63) / CPD)
+    const uint32_t *rowprof;       // [na + 1] dwords: bytes w(a, b) + 2g for b = 0..3; entry na = padding (-128)
+    const uint8_t *code1, *code2;  // [256] byte -> dense code
+    int pad_code;                  // = na
+    int gap;
+    int32_t *bnd;                  // [strips][m] bottom row of every strip, working-space scores
+    uint32_t *flags;               // [strips] 64-column blocks of bnd handed over so far
+    uint32_t *resid;               // [strips][words_per_strip][64 lanes]
+    uint32_t *status;              // != 0: a wait ran out (should never happen)
+    // traceback
+    const int32_t *table;          // na * nb scores as the caller gave them
+    int nb;
+    uint8_t gap_symbol;
+    int score_only;
+    int64_t *score;
+    uint8_t *t1, *t2;              // capacity n + m each, written right aligned
+    uint64_t *t_off, *t_len;
+};
+

@@ -34,6 +34,9 @@
 #include "device_helpers.h"
 
 #define BA_NEG (-(1 << 28))  // minus infinity of the E / F levels (align_affine.go:36-37, 45-46, 63-64)
+#ifndef BA_AFF_WPE
+#define BA_AFF_WPE 1  // wavefronts per SIMD the register allocator is asked to leave room for
+#endif
 
 // push the sign bit of t into the bottom of a bit plane
 __device__ __forceinline__ uint32_t ba_push_sign(uint32_t acc, int t)
@@ -42,14 +45,15 @@ __device__ __forceinline__ uint32_t ba_push_sign(uint32_t acc, int t)
 }
 
 // One column of one strip.  `top_hq`/`f` enter as hq and F' of the row above the strip.
-// Local mode clamps H' from below at its zero level ext*(i+j) -- wave-uniform, kept as a
-// running scalar (fl) -- and folds the best-cell search into one v_lshl_add + half a v_max3
-// per cell:  key = (true score << key_shift) | (first row of its pair ? 1 : 0) << jbits | (jmax - j),
+// Local mode clamps H' from below at its zero level ext*(i+j), a running value that steps
+// by ext per row, and folds the best-cell search into a subtract, a v_lshl_add and half a
+// v_max3 per cell:  key = (true score << key_shift) | (first row of its pair ? 1 : 0) << jbits | (jmax - j),
 // so the largest key of a row pair is its best cell, first in row-major order.
+// (klow0 / klow1: the low key bits for the even / odd rows of this column.)
 template <int MODE, int R>
 __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint32_t (&acc)[4], int (&rkey)[R / 2],
                                                  const uint32_t (&pw)[R / 4], int top_hq, int &f, int &topdiag, int c,
-                                                 int ge, int fl, int key_shift, int ks, int kstep, int pbit)
+                                                 int ge, int fl, int key_shift, int klow0, int klow1)
 {
     int up = top_hq, diag = topdiag;
     topdiag = top_hq;
@@ -64,14 +68,13 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
         const int d = diag + ba_sbyte(pw[r >> 2], r & 3);
         int H = ba_max3(en, fn, d);
         if (MODE == BA_LOCAL) {
-            fl += ge;      // zero level of row r: ext*(i+j)
-            ks -= kstep;   // (jmax - j) - (zero level << key_shift)
+            fl += ge;  // zero level of row r: ext*(i+j)
             H = max(H, fl);
         }
         acc[0] = ba_push_sign(acc[0], fn - H);
         acc[1] = ba_push_sign(acc[1], d - H);
         if (MODE == BA_LOCAL) {
-            const int key = (int)(((uint32_t)H << key_shift) + (uint32_t)(ks + ((r & 1) ? 0 : pbit)));
+            const int key = (int)(((uint32_t)(H - fl) << key_shift) + (uint32_t)((r & 1) ? klow1 : klow0));
             if (r & 1)
                 rkey[r / 2] = ba_max3(rkey[r / 2], kprev, key);
             else
@@ -90,8 +93,17 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
 //   [strip][column word cw = (j-1) / CPW][lane][plane 0..3]       CPW = 32 / R columns per word
 // bit 31 - ((j-1) % CPW * R + r) of a word belongs to row r of the strip.  The four planes
 // of one (strip, column word, lane) are one aligned uint4.
-template <int MODE, int R>
-__global__ void __launch_bounds__(256) ba_dp_affine_kernel(BaDpParams P)
+//
+// Two launch shapes:
+//   PIPE == false : one wavefront per bundle, strips one after the other (large batches:
+//                   the bundles alone fill the chip);
+//   PIPE == true  : one BLOCK per bundle; wave w takes strips w, w+W, w+2W, ... and the W
+//                   strips in flight form a pipeline over the columns: a strip may compute
+//                   a group of 4 columns once the strip above has handed over that group's
+//                   boundary row (written to global memory, announced through a progress
+//                   word in LDS).  W times as many wavefronts for batches of few, long pairs.
+template <int MODE, int R, bool PIPE>
+__global__ void __launch_bounds__(PIPE ? 512 : 256, BA_AFF_WPE) ba_dp_affine_kernel(BaDpParams P)
 {
     extern __shared__ __align__(16) uint32_t lds[];
     constexpr int HALVES = R / 16;
@@ -108,10 +120,14 @@ __global__ void __launch_bounds__(256) ba_dp_affine_kernel(BaDpParams P)
                                      : reinterpret_cast<const uint32_t *>(P.code2)[i - 64];
     const uint8_t *code1 = reinterpret_cast<const uint8_t *>(lds + wt_aligned);
     const uint8_t *code2 = code1 + 256;
+    // PIPE: progress words, one per wave: (round << 16) | column groups handed over so far
+    volatile uint32_t *prog = lds + wt_aligned + 128 + (size_t)waves * P.nb * (HALVES * 64 * 4);
+    int32_t *combine = reinterpret_cast<int32_t *>(lds + wt_aligned + 128 + (size_t)waves * P.nb * (HALVES * 64 * 4) + 8);
+    if (PIPE && threadIdx.x < 8) prog[threadIdx.x] = 0;
     __syncthreads();
 
-    const uint32_t b_idx = P.bundle_begin + blockIdx.x * waves + wave;
-    if (b_idx >= P.bundle_end) return;
+    const uint32_t b_idx = PIPE ? P.bundle_begin + blockIdx.x : P.bundle_begin + blockIdx.x * waves + wave;
+    if (b_idx >= P.bundle_end) return;  // (PIPE: the whole block leaves together)
     const BaBundle B = P.bundles[b_idx];
     const int n = (int)B.n, m = (int)B.m;
     const int ge = P.gap_ext, c = P.gap_open - P.gap_ext;
@@ -146,7 +162,29 @@ __global__ void __launch_bounds__(256) ba_dp_affine_kernel(BaDpParams P)
         best_sc = m >= 1 ? -P.gap_open - (m - 1) * ge : 0;
     }
 
-    for (int s = 0; s < strips; ++s) {
+    const int pred = (wave + waves - 1) % waves;  // PIPE: the wave that runs the strip above mine
+    uint32_t avail = 0;                           // PIPE: last progress word seen from it
+    for (int s = PIPE ? wave : 0; s < strips; s += PIPE ? waves : 1) {
+        const int round = PIPE ? s / waves : 0;
+        // progress word of the strip above once it has handed over `groups` column groups
+        const uint32_t pred_base = (uint32_t)(wave > 0 ? round : round - 1) << 16;
+        auto wait_for = [&](int groups) {
+            if (!PIPE || s == 0) return;
+            const uint32_t need = pred_base + (uint32_t)groups;
+            if (avail >= need) return;
+            // bounded: every wave leaves this loop even if something upstream went wrong
+            for (int spin = 0; spin < (1 << 26); ++spin) {
+                avail = prog[pred];
+                if (avail >= need) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        auto publish = [&](int groups) {
+            if (!PIPE) return;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the boundary stores are out before the word says so
+            prog[wave] = ((uint32_t)round << 16) + (uint32_t)groups;
+        };
         const int i0 = n - (strips - s) * R;
         const bool last_strip = (s == strips - 1);
         const int2 *bnd_rd = bnd + (size_t)((s + 1) & 1) * m * 64;
@@ -167,7 +205,7 @@ __global__ void __launch_bounds__(256) ba_dp_affine_kernel(BaDpParams P)
         uint4 *dirs = dir + (size_t)s * cws * 64;
         uint32_t acc[4] = {0, 0, 0, 0};
         // fitting / overlap hand the last strip's bottom row over as well: the end-cell scan reads it back
-        const bool write_bnd = !last_strip || MODE == BA_FITTING || MODE == BA_OVERLAP;
+        const bool write_bnd = true;  // (the last strip too: fitting / overlap scan it for the end cell; a conditional store costs registers)
 
         struct GroupIn {
             uint32_t sw;
@@ -177,6 +215,7 @@ __global__ void __launch_bounds__(256) ba_dp_affine_kernel(BaDpParams P)
             GroupIn gi;
             gi.sw = s2w[(size_t)cg * 64];
             if (s > 0) {
+                wait_for(cg + 1);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) gi.b[q] = bnd_rd[(size_t)min(cg * 4 + q, m - 1) * 64];
             } else {
@@ -208,9 +247,10 @@ __global__ void __launch_bounds__(256) ba_dp_affine_kernel(BaDpParams P)
                     // the row above the strip: row 0 (F = -inf, align_affine.go:63-64) or the previous strip's last row
                     const int top_hq = (s == 0) ? row0(j) - c : in.b[q].x;
                     int f = (s == 0) ? BA_NEG : in.b[q].y;
-                    const int fl0 = ge * (i0 + j);  // local: zero level of the row above the strip
+                    int fl0 = ge * (i0 + j);  // local: zero level of the row above the strip
+                    if (MODE == BA_LOCAL) asm volatile("v_mov_b32 %0, %1" : "=v"(fl0) : "s"(fl0));  // a per-lane chain, not 32 scalars
                     ba_affine_column<MODE, R>(hq, e, acc, rkey, pw, top_hq, f, topdiag, c, ge, fl0, key_shift,
-                                              (jmax - j) - (fl0 << key_shift), ge << key_shift, 1 << jbits);
+                                              (1 << jbits) + (jmax - j), jmax - j);
                     if ((j - 1) % CPW == CPW - 1)
                         dirs[(size_t)((j - 1) / CPW) * 64] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
                     if (write_bnd) bnd_wr[(size_t)(j - 1) * 64] = make_int2(hq[R - 1], f);
@@ -224,8 +264,12 @@ __global__ void __launch_bounds__(256) ba_dp_affine_kernel(BaDpParams P)
                 const GroupIn cur = nxt;
                 nxt = fetch_group(min(cg + 1, cgs - 1));
                 column_group(cg, cur, std::true_type{});
+                publish(cg + 1);
             }
-            if (full_groups < cgs) column_group(full_groups, nxt, std::false_type{});
+            if (full_groups < cgs) {
+                column_group(full_groups, nxt, std::false_type{});
+                publish(cgs);
+            }
             // a half-filled last word (R == 16, odd m): its column sits in the top half like any first column
             if (CPW == 2 && (m & 1))
                 dirs[(size_t)(m / 2) * 64] = make_uint4(acc[0] << 16, acc[1] << 16, acc[2] << 16, acc[3] << 16);
@@ -269,7 +313,31 @@ __global__ void __launch_bounds__(256) ba_dp_affine_kernel(BaDpParams P)
             }
         }
     }
-    if (lane < (int)B.count) {
+    bool writer = true;
+    if (PIPE) {
+        if (MODE == BA_LOCAL) {
+            // every wave holds the best cell of its own strips; the best of all is the largest
+            // score, on ties the smallest row (the waves' strips are disjoint)
+            combine[(wave * 3 + 0) * 64 + lane] = best_sc;
+            combine[(wave * 3 + 1) * 64 + lane] = best_i;
+            combine[(wave * 3 + 2) * 64 + lane] = best_j;
+            __syncthreads();
+            writer = (wave == 0);
+            if (writer)
+                for (int w = 1; w < waves; ++w) {
+                    const int sc = combine[(w * 3 + 0) * 64 + lane], ii = combine[(w * 3 + 1) * 64 + lane];
+                    if (sc > best_sc || (sc == best_sc && sc > 0 && ii < best_i)) {
+                        best_sc = sc;
+                        best_i = ii;
+                        best_j = combine[(w * 3 + 2) * 64 + lane];
+                    }
+                }
+        } else {
+            // the wave that ran the last strip knows the end cell (strips == 0: wave 0 holds the border case)
+            writer = strips > 0 ? (wave == (strips - 1) % waves) : (wave == 0);
+        }
+    }
+    if (writer && lane < (int)B.count) {
         BaLocalBest bb;
         bb.score = best_sc;  // true score of the end cell
         bb.i = best_i;
@@ -451,32 +519,43 @@ __global__ void __launch_bounds__(256) ba_trace_affine_kernel(BaTraceParams P)
 // ----------------------------------------------------------------------------
 extern "C" size_t ba_dp_linear_lds_bytes(int nb, int nb4, int na_pad, int R, int waves);
 
+// profile + tables as the linear kernel, plus the progress words and the best-cell exchange of PIPE
+extern "C" size_t ba_dp_affine_lds_bytes(int nb, int nb4, int na_pad, int R, int waves)
+{
+    return ba_dp_linear_lds_bytes(nb, nb4, na_pad, R, waves) + (8 + (size_t)waves * 3 * 64) * 4;
+}
+
 template <int MODE, int R>
-static hipError_t launch_dp_aff(const BaDpParams &P, int waves, hipStream_t st)
+static hipError_t launch_dp_aff(const BaDpParams &P, int waves, int pipe, hipStream_t st)
 {
     const uint32_t nbundles = P.bundle_end - P.bundle_begin;
-    const uint32_t blocks = (nbundles + waves - 1) / waves;
-    const size_t lds = ba_dp_linear_lds_bytes(P.nb, P.nb4, P.na_pad, R, waves);
-    hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R>), dim3(blocks), dim3(waves * 64), lds, st, P);
+    const size_t lds = ba_dp_affine_lds_bytes(P.nb, P.nb4, P.na_pad, R, waves);
+    if (pipe)
+        hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true>), dim3(nbundles), dim3(waves * 64), lds, st, P);
+    else
+        hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false>), dim3((nbundles + waves - 1) / waves),
+                           dim3(waves * 64), lds, st, P);
     return hipGetLastError();
 }
 
 template <int MODE>
-static hipError_t launch_dp_aff_mode(const BaDpParams &P, int R, int waves, hipStream_t st)
+static hipError_t launch_dp_aff_mode(const BaDpParams &P, int R, int waves, int pipe, hipStream_t st)
 {
-    if (R == 32) return launch_dp_aff<MODE, 32>(P, waves, st);
-    if (R == 16) return launch_dp_aff<MODE, 16>(P, waves, st);
+    if (R == 32) return launch_dp_aff<MODE, 32>(P, waves, pipe, st);
+    if (R == 16) return launch_dp_aff<MODE, 16>(P, waves, pipe, st);
     return hipErrorInvalidValue;
 }
 
-extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, int waves, hipStream_t st)
+// waves: wavefronts per block (pipe: 2..8, strips in flight per bundle; else 1..4 bundles per block)
+extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, int waves, int pipe, hipStream_t st)
 {
     if (P.bundle_end == P.bundle_begin) return hipSuccess;
+    if (waves < 1 || waves > (pipe ? 8 : 4)) return hipErrorInvalidValue;
     switch (mode) {
-    case BA_GLOBAL: return launch_dp_aff_mode<BA_GLOBAL>(P, R, waves, st);
-    case BA_LOCAL: return launch_dp_aff_mode<BA_LOCAL>(P, R, waves, st);
-    case BA_FITTING: return launch_dp_aff_mode<BA_FITTING>(P, R, waves, st);
-    case BA_OVERLAP: return launch_dp_aff_mode<BA_OVERLAP>(P, R, waves, st);
+    case BA_GLOBAL: return launch_dp_aff_mode<BA_GLOBAL>(P, R, waves, pipe, st);
+    case BA_LOCAL: return launch_dp_aff_mode<BA_LOCAL>(P, R, waves, pipe, st);
+    case BA_FITTING: return launch_dp_aff_mode<BA_FITTING>(P, R, waves, pipe, st);
+    case BA_OVERLAP: return launch_dp_aff_mode<BA_OVERLAP>(P, R, waves, pipe, st);
     }
     return hipErrorInvalidValue;
 }
