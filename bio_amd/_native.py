@@ -26,6 +26,7 @@ EXPORTS = (
     "bioalign_last_error",
     "bioalign_device_count",
     "bioalign_batch",
+    "bioalign_long",
     "bioalign_plan_create",
     "bioalign_plan_destroy",
     "bioalign_plan_workspace_bytes",
@@ -94,6 +95,8 @@ def lib():
         L.bioalign_device_count.argtypes = [C.c_void_p]
         L.bioalign_batch.restype = C.c_int
         L.bioalign_batch.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Result)]
+        L.bioalign_long.restype = C.c_int
+        L.bioalign_long.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Result), C.POINTER(C.c_float)]
         L.bioalign_plan_create.restype = C.c_void_p
         L.bioalign_plan_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(Batch)]
         L.bioalign_plan_destroy.argtypes = [C.c_void_p]
@@ -188,7 +191,11 @@ class Engine:
     def device_count(self) -> int:
         return lib().bioalign_device_count(self._h)
 
-    def batch(self, pb: PackedBatch):
+    def long(self, pb: PackedBatch):
+        """bioalign_long on host buffers -> (scores, t1, t2, t_off, t_len); self.last_kernel_ms is set."""
+        return self.batch(pb, long=True)
+
+    def batch(self, pb: PackedBatch, long: bool = False):
         """bioalign_batch on host buffers -> (scores, t1, t2, t_off, t_len)."""
         n = pb.n_pairs
         scores = np.zeros(max(n, 1), dtype=np.int64)
@@ -203,7 +210,12 @@ class Engine:
         if not score_only:
             r.t1, r.t2 = t1.ctypes.data, t2.ctypes.data
             r.t_off, r.t_len = t_off.ctypes.data, t_len.ctypes.data
-        rc = lib().bioalign_batch(self._h, C.byref(pb.c), C.byref(r))
+        if long:
+            ms = C.c_float()
+            rc = lib().bioalign_long(self._h, C.byref(pb.c), C.byref(r), C.byref(ms))
+            self.last_kernel_ms = ms.value
+        else:
+            rc = lib().bioalign_batch(self._h, C.byref(pb.c), C.byref(r))
         if rc != 0:
             self._raise(rc)
         return scores[:n], t1, t2, t_off[:n], t_len[:n]

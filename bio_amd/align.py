@@ -96,7 +96,10 @@ def pack_sequences(seqs):
     return data, off
 
 
-def _run_batch(mode, s1s, s2s, a, gap_open, gap_extend, score_only=False):
+LONG_MIN_CELLS = 1 << 24  # AlignGlobalLS hands pairs of at least this many cells to the long-mode kernels
+
+
+def _run_batch(mode, s1s, s2s, a, gap_open, gap_extend, score_only=False, long=False):
     if mode not in _native.MODES:
         raise KeyError(mode)
     d1, o1 = pack_sequences(s1s)
@@ -104,7 +107,7 @@ def _run_batch(mode, s1s, s2s, a, gap_open, gap_extend, score_only=False):
     table, code1, code2 = score_table(a, np.unique(d1).tolist(), np.unique(d2).tolist())
     pb = _native.PackedBatch(d1, o1, d2, o2, mode, table, code1, code2, gap_open, gap_extend,
                              gap_symbol=_gap(), flags=_native.SCORE_ONLY if score_only else 0)
-    scores, t1, t2, t_off, t_len = engine().batch(pb)
+    scores, t1, t2, t_off, t_len = engine().batch(pb, long=long)
     if score_only:
         return [int(x) for x in scores], None, None
     t1b, t2b = t1.tobytes(), t2.tobytes()
@@ -169,10 +172,22 @@ def AlignLocal(s1: bytes, s2: bytes, a, indelPenalty: int):
     return AlignPair("local", s1, s2, a, indelPenalty)
 
 
+def AlignPairLong(mode: str, s1: bytes, s2: bytes, a, indelPenalty: int):
+    """AlignPair for ONE long pair: same result, computed by the intra-sequence wavefront
+    kernels (bioalign_long).  global / fitting / overlap, linear gap, <= 4 column symbols."""
+    if mode not in _native.MODES:
+        return -1, None, None
+    sc, t1, t2 = _run_batch(mode, [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty, long=True)
+    return sc[0], t1[0], t2[0]
+
+
 def AlignGlobalLS(s1: bytes, s2: bytes, a, indelPenalty: int):
-    """align_linear.go:9-45.  The reference's function is WIP (panics, alternate
-    tie-breaks); this one returns exactly AlignGlobal's result, which is what its
-    author's disabled test asks for (align_test.go:55-66)."""
+    """align_linear.go:9-45, the reference's entry point for long inputs.  Its function is WIP
+    (panics, alternate tie-breaks); this one returns exactly AlignGlobal's result, which is what
+    its author's disabled test asks for (align_test.go:55-66).  Pairs of LONG_MIN_CELLS cells
+    or more go to the long-mode kernels when their parameters allow it."""
+    if len(s1) * len(s2) >= LONG_MIN_CELLS and len(set(bytes(s2))) <= 4:
+        return AlignPairLong("global", s1, s2, a, indelPenalty)
     return AlignPair("global", s1, s2, a, indelPenalty)
 
 

@@ -692,3 +692,183 @@ extern "C" int bioalign_batch(bioalign_ctx *ctx, const bioalign_batch_t *in, bio
         }
     return 0;
 }
+
+// ----------------------------------------------------------------------------
+// long mode: one pair at a time on the intra-sequence wavefront kernels (kernels_long.hip)
+// ----------------------------------------------------------------------------
+extern "C" int ba_long_rows_per_lane(int K);
+extern "C" hipError_t ba_launch_long(const BaLongParams &P, int mode, int T, int K, hipStream_t st);
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { (void)hipFree(p); }
+    int alloc(bioalign_ctx *ctx, size_t bytes)
+    {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess)
+            return ctx->fail(BIOALIGN_ENOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return 0;
+    }
+    template <class T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
+// one pair, n >= 1 and m >= 1, results into slot p of `out`
+int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *out, uint64_t p, float *dp_ms)
+{
+    const uint64_t a1 = in->s1_off[p], a2 = in->s2_off[p];
+    const uint64_t n = in->s1_off[p + 1] - a1, m = in->s2_off[p + 1] - a2;
+    const int g = in->gap_open;
+    const bool traces = !(in->flags & BIOALIGN_SCORE_ONLY);
+    if (in->nb > 4)
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode packs the scores of one row symbol into one dword: "
+                                                "at most 4 distinct column symbols (got %d)", in->nb);
+    int wmax = 0;
+    for (int i = 0; i < in->na * in->nb; ++i) {
+        const int64_t v = (int64_t)in->score_table[i] + 2 * g;
+        if (v < -127 || v > 127)
+            return ctx->fail(BIOALIGN_EUNSUPPORTED, "score %d with gap %d does not fit the int8 row profile",
+                             in->score_table[i], g);
+        wmax = std::max(wmax, in->score_table[i]);
+    }
+    const int64_t span = std::max<int64_t>((int64_t)wmax + 2 * (int64_t)g, 0) + 1;
+    const int K = span <= 4 ? 2 : span <= 16 ? 4 : span <= 256 ? 8 : 0;
+    if (!K) return ctx->fail(BIOALIGN_EUNSUPPORTED, "score span %lld does not fit 8 residue bits", (long long)span);
+    if ((n + m + 2) * 128 >= (1ull << 31))
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "pair too long for 32-bit working scores");
+    const int T = ba_long_rows_per_lane(K);
+    const int cpd = 32 / (T * K);
+    const uint64_t rs = 64ull * T;
+    const uint64_t strips = (n + rs - 1) / rs;
+    const uint64_t wps = (m + 63 + cpd - 1) / cpd;
+
+    std::vector<uint32_t> rowprof(in->na + 1, 0x80808080u);
+    for (int a = 0; a < in->na; ++a) {
+        uint32_t w = 0;
+        for (int b = 0; b < 4; ++b) {
+            const int v = b < in->nb ? in->score_table[a * in->nb + b] + 2 * g : -128;
+            w |= (uint32_t)(uint8_t)(int8_t)v << (8 * b);
+        }
+        rowprof[a] = w;
+    }
+
+    HIP_TRY(ctx, hipSetDevice(ctx->devices[0]));
+    DevBuf d_s1, d_s2, d_prof, d_c1, d_c2, d_tab, d_bnd, d_flags, d_res, d_misc, d_t1, d_t2;
+    int rc;
+    if ((rc = d_s1.alloc(ctx, n + 16)) || (rc = d_s2.alloc(ctx, m + 16)) || (rc = d_prof.alloc(ctx, rowprof.size() * 4)) ||
+        (rc = d_c1.alloc(ctx, 256)) || (rc = d_c2.alloc(ctx, 256)) || (rc = d_tab.alloc(ctx, (size_t)in->na * in->nb * 4)) ||
+        (rc = d_bnd.alloc(ctx, strips * m * 4)) || (rc = d_flags.alloc(ctx, strips * 4 + 4)) ||
+        (rc = d_res.alloc(ctx, strips * wps * 256)) || (rc = d_misc.alloc(ctx, 64)))
+        return rc;
+    const uint64_t cap = n + m;
+    if (traces && ((rc = d_t1.alloc(ctx, cap + 32)) || (rc = d_t2.alloc(ctx, cap + 32)))) return rc;
+    hipStream_t st = nullptr;
+    HIP_TRY(ctx, hipMemcpyAsync(d_s1.p, in->s1 + a1, n, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_s2.p, in->s2 + a2, m, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_prof.p, rowprof.data(), rowprof.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_c1.p, in->code1, 256, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_c2.p, in->code2, 256, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_tab.p, in->score_table, (size_t)in->na * in->nb * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(d_flags.p, 0, strips * 4 + 4, st));
+    HIP_TRY(ctx, hipMemsetAsync(d_misc.p, 0, 64, st));
+
+    BaLongParams P;
+    P.s1 = d_s1.as<uint8_t>();
+    P.s2 = d_s2.as<uint8_t>();
+    P.n = (uint32_t)n;
+    P.m = (uint32_t)m;
+    P.strips = (uint32_t)strips;
+    P.words_per_strip = (uint32_t)wps;
+    P.rowprof = d_prof.as<uint32_t>();
+    P.code1 = d_c1.as<uint8_t>();
+    P.code2 = d_c2.as<uint8_t>();
+    P.pad_code = in->na;
+    P.gap = g;
+    P.bnd = d_bnd.as<int32_t>();
+    P.flags = d_flags.as<uint32_t>();
+    P.resid = d_res.as<uint32_t>();
+    // misc: [0] status, [8] score, [16] t_off, [24] t_len
+    P.status = d_misc.as<uint32_t>();
+    P.table = d_tab.as<int32_t>();
+    P.nb = in->nb;
+    P.gap_symbol = in->gap_symbol;
+    P.score_only = traces ? 0 : 1;
+    P.score = reinterpret_cast<int64_t *>(d_misc.as<uint8_t>() + 8);
+    P.t1 = d_t1.as<uint8_t>();
+    P.t2 = d_t2.as<uint8_t>();
+    P.t_off = reinterpret_cast<uint64_t *>(d_misc.as<uint8_t>() + 16);
+    P.t_len = reinterpret_cast<uint64_t *>(d_misc.as<uint8_t>() + 24);
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipEventRecord(e0, st));
+    hipError_t le = ba_launch_long(P, in->mode, T, K, st);
+    if (le == hipSuccess) le = hipEventRecord(e1, st);
+    uint64_t misc[8] = {0};
+    if (le == hipSuccess) le = hipMemcpyAsync(misc, d_misc.p, 64, hipMemcpyDeviceToHost, st);
+    if (le == hipSuccess) le = hipStreamSynchronize(st);
+    float ms = 0.f;
+    if (le == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (le != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "long-mode kernels failed: %s", hipGetErrorString(le));
+    if (dp_ms) *dp_ms += ms;
+    if ((uint32_t)misc[0] != 0)
+        return ctx->fail(BIOALIGN_EHIP, "long mode: a strip gave up waiting for the strip above it (%u waits ran out)",
+                         (unsigned)(uint32_t)misc[0]);
+    out->scores[p] = (int64_t)misc[1];
+    if (traces) {
+        const uint64_t slot = a1 + a2, off = misc[2], len = misc[3];
+        if (off + len != cap) return ctx->fail(BIOALIGN_EHIP, "long mode: inconsistent trace extent");
+        HIP_TRY(ctx, hipMemcpy(out->t1 + slot + off, d_t1.as<uint8_t>() + off, len, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(out->t2 + slot + off, d_t2.as<uint8_t>() + off, len, hipMemcpyDeviceToHost));
+        out->t_off[p] = slot + off;
+        out->t_len[p] = len;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int bioalign_long(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *out, float *kernel_ms)
+{
+    if (!ctx) return BIOALIGN_EINVAL;
+    if (!in || !out) return ctx->fail(BIOALIGN_EINVAL, "null argument");
+    if (!in->s1_off || !in->s2_off || !in->score_table || !in->code1 || !in->code2)
+        return ctx->fail(BIOALIGN_EINVAL, "null offsets / score table / code maps");
+    if (in->mode < BIOALIGN_GLOBAL || in->mode > BIOALIGN_OVERLAP) return ctx->fail(BIOALIGN_EINVAL, "unknown mode %d", in->mode);
+    if (in->na <= 0 || in->nb <= 0 || in->na > 255 || in->nb > 255)
+        return ctx->fail(BIOALIGN_EINVAL, "alphabet sizes must be in 1..255 (got %d, %d)", in->na, in->nb);
+    const uint64_t N = in->n_pairs;
+    if (N == 0) return 0;
+    if (!out->scores) return ctx->fail(BIOALIGN_EINVAL, "null scores buffer");
+    const bool traces = !(in->flags & BIOALIGN_SCORE_ONLY);
+    if (traces && (!out->t1 || !out->t2 || !out->t_off || !out->t_len))
+        return ctx->fail(BIOALIGN_EINVAL, "trace buffers are required unless BIOALIGN_SCORE_ONLY is set");
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (in->gap_open != in->gap_extend)
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode covers linear gaps only (affine: use bioalign_batch)");
+    if (in->mode == BIOALIGN_LOCAL)
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode covers global, fitting and overlap (local: use bioalign_batch)");
+    if (in->gap_open < 0) return ctx->fail(BIOALIGN_EUNSUPPORTED, "negative gap penalty %d", in->gap_open);
+    for (uint64_t p = 0; p < N; ++p) {
+        const uint64_t n = in->s1_off[p + 1] - in->s1_off[p], m = in->s2_off[p + 1] - in->s2_off[p];
+        int rc;
+        if (n == 0 || m == 0) {
+            // nothing to parallelise inside the pair: the batch kernels handle the borders
+            std::string err;
+            rc = run_share(ctx, 0, in, out, p, p + 1, &err);
+            if (rc) {
+                ctx->err = err;
+                ctx->code = rc;
+            }
+        } else {
+            rc = long_pair(ctx, in, out, p, kernel_ms);
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}

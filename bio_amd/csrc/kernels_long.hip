@@ -139,7 +139,10 @@ __global__ void __launch_bounds__(64) ba_long_dp_kernel(BaLongParams P)
                         if (seen >= need) break;
                         __builtin_amdgcn_s_sleep(8);
                     }
-                    if (spin == (1 << 22)) failed = true;
+                    if (spin == (1 << 22)) {  // give up waiting for good; the host reports the run as failed
+                        failed = true;
+                        seen = BA_LONG_FINAL;
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 bin = col < m ? __hip_atomic_load(bnd_in + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;

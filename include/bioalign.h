@@ -152,6 +152,18 @@ int bioalign_plan_run(bioalign_plan *plan, const uint8_t *d_s1, const uint64_t *
                       uint64_t *d_t_off, uint64_t *d_t_len, void *stream);
 
 /*
+ * Long mode: the same call shape as bioalign_batch, but every pair is aligned on its own by
+ * the intra-sequence kernels -- rows spread over the lanes of many wavefronts, anti-diagonal
+ * wavefront, strips pipelined through HBM -- which is what a single long pair needs
+ * (AlignGlobalLS, align_linear.go:9, on inputs the per-lane batch kernels would crawl through;
+ * AlignPair "global" / "fitting" / "overlap", align_pair.go:3, likewise).  Linear gaps, at most
+ * 4 distinct column symbols; anything else answers BIOALIGN_EUNSUPPORTED.  Runs on the first
+ * device of the context.  kernel_ms (may be NULL) receives the summed DP + traceback kernel
+ * time in milliseconds.
+ */
+int bioalign_long(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *out, float *kernel_ms);
+
+/*
  * Timing hooks for the benchmark (no counterpart in the reference): the plan
  * records a pair of HIP events around every DP kernel launch, on the launch
  * stream, into a fixed pool of 256 pairs.  Once the stream has been
