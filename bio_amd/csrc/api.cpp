@@ -98,6 +98,11 @@ struct bioalign_plan {
     std::vector<hipEvent_t> ev0, ev1;
     size_t ev_used = 0;
     bool ran = false;
+    // traceback of slice k runs on a second stream while the DP kernel of slice k+1 runs on the caller's
+    int slices = 1;
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_slice;
+    hipEvent_t ev_side_done = nullptr;
     std::vector<void *> allocs;
 };
 
@@ -177,6 +182,9 @@ extern "C" void bioalign_plan_destroy(bioalign_plan *pl)
     for (void *p : pl->allocs) (void)hipFree(p);
     for (hipEvent_t e : pl->ev0) (void)hipEventDestroy(e);
     for (hipEvent_t e : pl->ev1) (void)hipEventDestroy(e);
+    for (hipEvent_t e : pl->ev_slice) (void)hipEventDestroy(e);
+    if (pl->ev_side_done) (void)hipEventDestroy(pl->ev_side_done);
+    if (pl->side) (void)hipStreamDestroy(pl->side);
     delete pl;
 }
 
@@ -399,6 +407,22 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     HIP_TRY(ctx, hipMemcpy(pl->d_code2, in->code2, 256, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(pl->d_table, in->score_table, (size_t)pl->na * pl->nb * 4, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(pl->d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+    // Large batches: cut every chunk into slices so that the (latency-bound) traceback of one slice
+    // overlaps the (VALU-bound) DP of the next.  Slices have disjoint workspace by construction.
+    {
+        size_t biggest = 0;
+        for (const Chunk &c : pl->chunks) biggest = std::max<size_t>(biggest, c.bundle_end - c.bundle_begin);
+        // Off by default: measured on MI355X (profiles/r01_notes.md) the two kernels contend for the same CUs and the
+        // step gets slower (10.5 -> 11.4 ms with 4 slices, 13.4 ms with 8); BIOALIGN_SLICES=n turns it on.
+        const uint64_t want = env_u64("BIOALIGN_SLICES", 1);
+        pl->slices = (!pl->score_only && biggest >= 4096 && want > 1) ? (int)std::min<uint64_t>(want, 16) : 1;
+        if (pl->slices > 1) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
+            pl->ev_slice.resize(pl->slices);
+            for (auto &e : pl->ev_slice) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_side_done, hipEventDisableTiming));
+        }
+    }
     const size_t pool = 256;
     pl->ev0.resize(pool);
     pl->ev1.resize(pool);
@@ -460,71 +484,88 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         pk.rows_per_strip = pl->R;
         HIP_TRY(ctx, ba_launch_pack(pk, st));
 
-        BaDpParams dp;
-        dp.bundles = pl->d_bundles;
-        dp.bundle_begin = ch.bundle_begin;
-        dp.bundle_end = ch.bundle_end;
-        dp.s1w = pl->d_s1w;
-        dp.s2w = pl->d_s2w;
-        dp.hb = pl->d_hb;
-        dp.dir = pl->d_dir;
-        dp.best = pl->d_best;
-        dp.wt = pl->d_wt;
-        dp.code1 = pl->d_code1;
-        dp.code2 = pl->d_code2;
-        dp.pad_code = pl->na;
-        dp.nb = pl->nb;
-        dp.nb4 = pl->nb4;
-        dp.na_pad = pl->na_pad;
-        dp.gap = pl->gap;
-        dp.gap_open = pl->gap_open;
-        dp.gap_ext = pl->gap_ext;
-        const bool timed = pl->ev_used < pl->ev0.size();
-        if (timed) HIP_TRY(ctx, hipEventRecord(pl->ev0[pl->ev_used], st));
-        if (pl->affine)
-            HIP_TRY(ctx, ba_launch_dp_affine(dp, pl->mode, pl->R, pl->waves, pl->pipe, st));
-        else
-            HIP_TRY(ctx, ba_launch_dp_linear(dp, pl->mode, pl->R, pl->K, pl->waves, st));
-        if (timed) {
-            HIP_TRY(ctx, hipEventRecord(pl->ev1[pl->ev_used], st));
-            ++pl->ev_used;
-        }
+        const uint32_t nbun = ch.bundle_end - ch.bundle_begin;
+        const int slices = pl->slices > 1 && nbun >= 4096 ? pl->slices : 1;
+        for (int k = 0; k < slices; ++k) {
+            const uint32_t b0 = ch.bundle_begin + (uint32_t)((uint64_t)nbun * k / slices);
+            const uint32_t b1 = ch.bundle_begin + (uint32_t)((uint64_t)nbun * (k + 1) / slices);
+            BaDpParams dp;
+            dp.bundles = pl->d_bundles;
+            dp.bundle_begin = b0;
+            dp.bundle_end = b1;
+            dp.s1w = pl->d_s1w;
+            dp.s2w = pl->d_s2w;
+            dp.hb = pl->d_hb;
+            dp.dir = pl->d_dir;
+            dp.best = pl->d_best;
+            dp.wt = pl->d_wt;
+            dp.code1 = pl->d_code1;
+            dp.code2 = pl->d_code2;
+            dp.pad_code = pl->na;
+            dp.nb = pl->nb;
+            dp.nb4 = pl->nb4;
+            dp.na_pad = pl->na_pad;
+            dp.gap = pl->gap;
+            dp.gap_open = pl->gap_open;
+            dp.gap_ext = pl->gap_ext;
+            const bool timed = pl->ev_used < pl->ev0.size();
+            if (timed) HIP_TRY(ctx, hipEventRecord(pl->ev0[pl->ev_used], st));
+            if (pl->affine)
+                HIP_TRY(ctx, ba_launch_dp_affine(dp, pl->mode, pl->R, pl->waves, pl->pipe, st));
+            else
+                HIP_TRY(ctx, ba_launch_dp_linear(dp, pl->mode, pl->R, pl->K, pl->waves, st));
+            if (timed) {
+                HIP_TRY(ctx, hipEventRecord(pl->ev1[pl->ev_used], st));
+                ++pl->ev_used;
+            }
 
-        BaTraceParams tr;
-        tr.bundles = pl->d_bundles;
-        tr.bundle_begin = ch.bundle_begin;
-        tr.bundle_end = ch.bundle_end;
-        tr.perm = pl->d_perm;
-        tr.s1 = d_s1;
-        tr.s2 = d_s2;
-        tr.s1_off = d_s1_off;
-        tr.s2_off = d_s2_off;
-        tr.code1 = pl->d_code1;
-        tr.code2 = pl->d_code2;
-        tr.table = pl->d_table;
-        tr.na = pl->na;
-        tr.nb = pl->nb;
-        tr.s1w = pl->d_s1w;
-        tr.s2w = pl->d_s2w;
-        tr.hb = pl->d_hb;
-        tr.dir = pl->d_dir;
-        tr.best = pl->d_best;
-        tr.gap = pl->gap;
-        tr.gap_open = pl->gap_open;
-        tr.gap_ext = pl->gap_ext;
-        tr.rows_per_strip = pl->R;
-        tr.residue_bits = pl->K;
-        tr.score_only = pl->score_only ? 1 : 0;
-        tr.gap_symbol = pl->gap_symbol;
-        tr.scores = d_scores;
-        tr.t1 = d_t1;
-        tr.t2 = d_t2;
-        tr.t_off = d_t_off;
-        tr.t_len = d_t_len;
-        if (pl->affine)
-            HIP_TRY(ctx, ba_launch_trace_affine(tr, pl->mode, pl->R, st));
-        else
-            HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, st));
+            hipStream_t ts = st;
+            if (slices > 1) {
+                ts = pl->side;
+                HIP_TRY(ctx, hipEventRecord(pl->ev_slice[k], st));
+                HIP_TRY(ctx, hipStreamWaitEvent(ts, pl->ev_slice[k], 0));
+            }
+            BaTraceParams tr;
+            tr.bundles = pl->d_bundles;
+            tr.bundle_begin = b0;
+            tr.bundle_end = b1;
+            tr.perm = pl->d_perm;
+            tr.s1 = d_s1;
+            tr.s2 = d_s2;
+            tr.s1_off = d_s1_off;
+            tr.s2_off = d_s2_off;
+            tr.code1 = pl->d_code1;
+            tr.code2 = pl->d_code2;
+            tr.table = pl->d_table;
+            tr.na = pl->na;
+            tr.nb = pl->nb;
+            tr.s1w = pl->d_s1w;
+            tr.s2w = pl->d_s2w;
+            tr.hb = pl->d_hb;
+            tr.dir = pl->d_dir;
+            tr.best = pl->d_best;
+            tr.gap = pl->gap;
+            tr.gap_open = pl->gap_open;
+            tr.gap_ext = pl->gap_ext;
+            tr.rows_per_strip = pl->R;
+            tr.residue_bits = pl->K;
+            tr.score_only = pl->score_only ? 1 : 0;
+            tr.gap_symbol = pl->gap_symbol;
+            tr.scores = d_scores;
+            tr.t1 = d_t1;
+            tr.t2 = d_t2;
+            tr.t_off = d_t_off;
+            tr.t_len = d_t_len;
+            if (pl->affine)
+                HIP_TRY(ctx, ba_launch_trace_affine(tr, pl->mode, pl->R, ts));
+            else
+                HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, ts));
+        }
+        if (slices > 1) {
+            // the caller's stream owns the results (and the workspace, for the next chunk or run) again
+            HIP_TRY(ctx, hipEventRecord(pl->ev_side_done, pl->side));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_side_done, 0));
+        }
     }
     pl->ran = true;
     return 0;

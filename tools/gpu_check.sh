@@ -14,7 +14,7 @@ import sys, json
 for l in sys.stdin:
     d = json.loads(l)
     print('value', d['value'], 'ms/step', d['ms_per_step'], 'parity', d.get('parity_check'))
-    for k in d['roofline']['kernels']: print('  ', k['kernel'], k['avg_ms'], 'ms', k['gcups'], 'GCUPS frac', k['frac'])
+    for k in d['roofline']['kernels']: print('  ', k['kernel'], k['pass_ms'], 'ms/pass', k['gcups'], 'GCUPS frac', k['frac'])
 "
 cat gpurun_out/$tag/prof/*/*kernel_stats.csv | python3 -c "import sys,csv
 for r in csv.reader(sys.stdin):
