@@ -796,7 +796,7 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     }
 
     HIP_TRY(ctx, hipSetDevice(ctx->devices[0]));
-    DevBuf d_s1, d_s2, d_prof, d_c1, d_c2, d_tab, d_bnd, d_flags, d_res, d_misc, d_t1, d_t2;
+    DevBuf d_s1, d_s2, d_prof, d_c1, d_c2, d_tab, d_bnd, d_flags, d_res, d_misc, d_t1, d_t2, d_ops;
     int rc;
     if ((rc = d_s1.alloc(ctx, n + 16)) || (rc = d_s2.alloc(ctx, m + 16)) || (rc = d_prof.alloc(ctx, rowprof.size() * 4)) ||
         (rc = d_c1.alloc(ctx, 256)) || (rc = d_c2.alloc(ctx, 256)) || (rc = d_tab.alloc(ctx, (size_t)in->na * in->nb * 4)) ||
@@ -804,7 +804,9 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
         (rc = d_res.alloc(ctx, strips * wps * 256)) || (rc = d_misc.alloc(ctx, 64)))
         return rc;
     const uint64_t cap = n + m;
-    if (traces && ((rc = d_t1.alloc(ctx, cap + 32)) || (rc = d_t2.alloc(ctx, cap + 32)))) return rc;
+    if (traces && ((rc = d_t1.alloc(ctx, cap + 32)) || (rc = d_t2.alloc(ctx, cap + 32)) ||
+                   (rc = d_ops.alloc(ctx, (cap / 16 + 2) * 4))))
+        return rc;
     hipStream_t st = nullptr;
     HIP_TRY(ctx, hipMemcpyAsync(d_s1.p, in->s1 + a1, n, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d_s2.p, in->s2 + a2, m, hipMemcpyHostToDevice, st));
@@ -830,7 +832,7 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     P.bnd = d_bnd.as<int32_t>();
     P.flags = d_flags.as<uint32_t>();
     P.resid = d_res.as<uint32_t>();
-    // misc: [0] status, [8] score, [16] t_off, [24] t_len
+    // misc: [0] status, [8] score, [16] t_off, [24] t_len, [32..43] walk
     P.status = d_misc.as<uint32_t>();
     P.table = d_tab.as<int32_t>();
     P.nb = in->nb;
@@ -841,6 +843,8 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     P.t2 = d_t2.as<uint8_t>();
     P.t_off = reinterpret_cast<uint64_t *>(d_misc.as<uint8_t>() + 16);
     P.t_len = reinterpret_cast<uint64_t *>(d_misc.as<uint8_t>() + 24);
+    P.walk = reinterpret_cast<uint32_t *>(d_misc.as<uint8_t>() + 32);
+    P.ops = d_ops.as<uint32_t>();
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(ctx, hipEventCreate(&e0));

@@ -82,6 +82,8 @@ struct BaTraceParams {
     int64_t *scores;
     uint8_t *t1, *t2;
     uint64_t *t_off, *t_len;
+    uint32_t *ops;                 // 2-bit move codes of the walk, 16 per dword, last column first
+    uint32_t *walk;                // [0], [1]: end cell (i, j); [2]: number of moves
 };
 
 // ----------------------------------------------------------------------------
@@ -111,5 +113,7 @@ struct BaLongParams {
     int64_t *score;
     uint8_t *t1, *t2;              // capacity n + m each, written right aligned
     uint64_t *t_off, *t_len;
+    uint32_t *ops;                 // 2-bit move codes of the walk, 16 per dword, last column first
+    uint32_t *walk;                // [0], [1]: end cell (i, j); [2]: number of moves
 };
 

@@ -192,31 +192,40 @@ __global__ void __launch_bounds__(64) ba_long_dp_kernel(BaLongParams P)
 }
 
 // ----------------------------------------------------------------------------
-// traceback, long mode: one wavefront walks the path back from the end cell; all lanes
-// run the same walk (uniform control flow, LDS broadcasts) over residue tiles staged in
-// LDS: the tile of the current strip (64 residue words x 64 lanes, one contiguous 16 KB
-// block of HBM) and, for the rows that touch the strip above, that strip's last lane.
+// traceback, long mode, in two kernels.
+//
+// (1) The WALK.  In the working space a cell is cur = max3(up, left, diag + w) with the
+// reference's order up > left > diagonal on ties (align.go:105-116), so
+//     diagonal  <=>  cur > up and cur > left
+//     left      <=>  cur == left and cur > up
+//     up        <=>  otherwise
+// and cur - up, cur - left lie in 0 .. max(w) + 2g < 2^K: both tests read off the K-bit
+// residues alone, (rho(cur) - rho(up)) mod 2^K != 0.  The walk therefore needs no scores,
+// no symbols and no score table: three residues per move (border cells have the residues
+// of their closed-form scores).  One wavefront walks (all lanes the same walk: uniform
+// control flow, LDS broadcasts) over residue tiles staged in LDS -- the tile of the
+// current strip (64 residue words x 64 lanes = one contiguous 16 KB block of HBM) and, for
+// the rows that touch the strip above, that strip's last lane -- and emits one 2-bit move
+// code per step, 16 to a dword.
+//
+// (2) The EXPANSION of the move codes into the two gapped byte strings (align.go:126-143;
+// align_pair.go:197-216) is a prefix sum: one block, 1024 threads.
 // ----------------------------------------------------------------------------
+enum { BA_MV_UP = 0, BA_MV_LEFT = 1, BA_MV_DIAG = 2 };
+
 template <int MODE, int T, int K>
-__global__ void __launch_bounds__(64) ba_long_trace_kernel(BaLongParams P)
+__global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
 {
     using G = BaLongGeom<T, K>;
     constexpr int RS = G::RS, CPD = G::CPD;
     constexpr uint32_t MASK = (1u << K) - 1u;
     __shared__ uint32_t tile[64 * 64];
     __shared__ uint32_t above[64];
-    __shared__ uint32_t seqbuf[2][64];  // 256 bytes of s1 / s2 around the walk
-    __shared__ uint32_t code1s[64], code2s[64];
     const int lane = threadIdx.x;
     const int n = (int)P.n, m = (int)P.m, g = P.gap;
     const int strips = (int)P.strips;
     const int front = strips * RS - n;
-    const size_t wps = P.words_per_strip;
-    code1s[lane] = reinterpret_cast<const uint32_t *>(P.code1)[lane];
-    code2s[lane] = reinterpret_cast<const uint32_t *>(P.code2)[lane];
-    const uint8_t *code1 = reinterpret_cast<const uint8_t *>(code1s);
-    const uint8_t *code2 = reinterpret_cast<const uint8_t *>(code2s);
-    __syncthreads();
+    const int wps = (int)P.words_per_strip;
 
     const int b_top = (MODE == BA_FITTING) ? g : 0;
     const int b_left = (MODE == BA_OVERLAP) ? g : 0;
@@ -236,9 +245,8 @@ __global__ void __launch_bounds__(64) ba_long_trace_kernel(BaLongParams P)
             const int hv = col < m ? bottom_row[col] : 0;
             int v = col < m ? hv - g * (col + 1) : INT32_MIN;
             int jj = col + 1, cc = hv;
-            // wave argmax, smaller column wins ties
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
+            for (int d = 1; d < 64; d <<= 1) {  // wave argmax, smaller column wins ties
                 const int ov = __shfl_xor(v, d), oj = __shfl_xor(jj, d), oc = __shfl_xor(cc, d);
                 if (ov > v || (ov == v && oj < jj)) {
                     v = ov;
@@ -255,52 +263,40 @@ __global__ void __launch_bounds__(64) ba_long_trace_kernel(BaLongParams P)
         j = bj;
         cur = bc;
     }
-    if (lane == 0) *P.score = (int64_t)cur - (int64_t)g * (i + j);
+    j = __builtin_amdgcn_readfirstlane(j);
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    if (lane == 0) {
+        *P.score = (int64_t)cur - (int64_t)g * (i + j);
+        P.walk[0] = (uint32_t)i;  // where the walk starts
+        P.walk[1] = (uint32_t)j;
+    }
     if (P.score_only) return;
-
-    BaBackWriter w1, w2;
-    const uint64_t cap = (uint64_t)n + (uint64_t)m;
-    w1.init(P.t1, cap);
-    w2.init(P.t2, cap);
-    const uint32_t gs = P.gap_symbol;
-    const int wbias = 2 * g;
-
-    // staged sequence bytes: seqbuf[k] holds bytes [base_k, base_k + 256)
-    int base1 = -1, base2 = -1;
-    auto sym = [&](int which, const uint8_t *src, int len, int idx, int &base) {  // src[idx]
-        if (base < 0 || idx < base || idx >= base + 256) {
-            base = max(0, idx - 252) & ~3;  // idx lands in the last dword of the window
-            uint32_t v = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int a = base + lane * 4 + b;
-                v |= (a < len ? (uint32_t)src[a] : 0u) << (8 * b);
-            }
-            seqbuf[which][lane] = v;
-        }
-        return (uint32_t)reinterpret_cast<const uint8_t *>(seqbuf[which])[idx - base];
-    };
 
     // residue tiles
     int tile_s = -1, tile_u = 0;   // strip and first word index of `tile`
     int ab_s = -1, ab_u = 0;       // strip and first word index of `above` (lane 63 of that strip)
     auto load_tile = [&](int s, int u) {
         tile_s = s;
-        tile_u = max(0, min(u - 63 + 8, (int)wps - 64));  // the walk moves towards smaller words
-        tile_u = max(tile_u, 0);
+        tile_u = max(0, min(u - 55, wps - 64));  // the walk moves towards smaller words
         const uint32_t *src = P.resid + ((size_t)s * wps + tile_u) * 64;
-        const int words = min(64, (int)wps - tile_u);
-#pragma unroll 4
-        for (int q = 0; q < 64; ++q) tile[q * 64 + lane] = q < words ? src[(size_t)q * 64 + lane] : 0u;
+        const int words = min(64, wps - tile_u);
+        // all 64 loads in flight at once: one memory latency per tile, not eight
+        uint32_t v[64];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) v[q] = src[(size_t)min(q, words - 1) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) tile[q * 64 + lane] = v[q];
     };
     auto load_above = [&](int s, int u) {
         ab_s = s;
-        ab_u = max(0, min(u - 63 + 8, (int)wps - 64));
+        ab_u = max(0, min(u - 55, wps - 64));
         const int uu = ab_u + lane;
-        above[lane] = uu < (int)wps ? P.resid[((size_t)s * wps + uu) * 64 + 63] : 0u;
+        above[lane] = uu < wps ? P.resid[((size_t)s * wps + uu) * 64 + 63] : 0u;
     };
-    // residue of cell (ii, jj), 1 <= ii <= n, 1 <= jj <= m
-    auto residue = [&](int ii, int jj) {
+    // residue of cell (ii, jj), 0 <= ii <= n, 0 <= jj <= m
+    auto residue = [&](int ii, int jj) -> uint32_t {
+        if (ii == 0) return (uint32_t)(b_top * jj) & MASK;   // Hs(0, j) = b_top * j
+        if (jj == 0) return (uint32_t)(b_left * ii) & MASK;  // Hs(i, 0) = b_left * i
         const int tt = ii - 1 + front;
         const int s = tt / RS, l = (tt % RS) / T, r = tt % T;
         const int t = (jj - 1) + l;
@@ -315,56 +311,165 @@ __global__ void __launch_bounds__(64) ba_long_trace_kernel(BaLongParams P)
             if (s != ab_s || u < ab_u || u >= ab_u + 64) load_above(s, u);
             word = above[u - ab_u];
         }
+        // every lane read the same word: say so, and the whole walk runs on the scalar unit
+        word = (uint32_t)__builtin_amdgcn_readfirstlane((int)word);
         return (word >> sh) & MASK;
     };
-    auto neighbour = [&](int c, uint32_t rho) { return c - (int)(((uint32_t)c - rho) & MASK); };
 
-    while (i > 0 && j > 0) {
-        const int up = (i == 1) ? b_top * j : neighbour(cur, residue(i - 1, j));
-        const int left = (j == 1) ? b_left * i : neighbour(cur, residue(i, j - 1));
-        const int diag = (i == 1) ? b_top * (j - 1) : (j == 1) ? b_left * (i - 1) : neighbour(up, residue(i - 1, j - 1));
-        const uint32_t x = sym(0, P.s1, n, i - 1, base1);
-        const uint32_t y = sym(1, P.s2, m, j - 1, base2);
-        const int w = P.table[(int)code1[x] * P.nb + (int)code2[y]] + wbias;
-        const int d = diag + w;
-        const int mx = max(up, left);
-        if (d > mx) {
-            w1.put(x);
-            w2.put(y);
-            cur = diag;
-            --i;
-            --j;
-        } else if (left > up) {
-            w1.put(gs);
-            w2.put(y);
-            cur = left;
-            --j;
+    // The same lookup without loading anything: per-lane cell, says whether the staged tiles hold it
+    auto peek = [&](int ii, int jj, bool &ok) -> uint32_t {
+        if (ii == 0) return (uint32_t)(b_top * jj) & MASK;
+        if (jj == 0) return (uint32_t)(b_left * ii) & MASK;
+        const int tt = ii - 1 + front;
+        const int s = tt / RS, l = (tt % RS) / T, r = tt % T;
+        const int t = (jj - 1) + l;
+        const int u = t / CPD;
+        const uint32_t sh = (uint32_t)(((t % CPD) * T + r) * K);
+        uint32_t word = 0;
+        if (s == tile_s || l != 63) {
+            const bool in = (s == tile_s) && u >= tile_u && u < tile_u + 64;
+            ok = ok && in;
+            word = tile[(in ? (u - tile_u) : 0) * 64 + l];
         } else {
-            w1.put(x);
-            w2.put(gs);
-            cur = up;
-            --i;
+            const bool in = (s == ab_s) && u >= ab_u && u < ab_u + 64;
+            ok = ok && in;
+            word = above[in ? (u - ab_u) : 0];
+        }
+        return (word >> sh) & MASK;
+    };
+
+    // move codes: 64-bit accumulator, flushed two dwords at a time
+    uint32_t *ops = P.ops;
+    uint64_t opacc = 0;
+    uint32_t fill = 0;   // codes in opacc
+    uint32_t k = 0;      // codes flushed so far
+    auto emit_run = [&](uint32_t mv, uint32_t count) {
+        const uint64_t pattern = mv == BA_MV_DIAG ? 0xAAAAAAAAAAAAAAAAull : mv == BA_MV_LEFT ? 0x5555555555555555ull : 0ull;
+        while (count > 0) {
+            const uint32_t c = min(count, 32u - fill);
+            const uint64_t bits = c == 32 ? pattern : (pattern & ((1ull << (2 * c)) - 1ull));
+            opacc |= bits << (2 * fill);
+            fill += c;
+            count -= c;
+            if (fill == 32) {
+                if (lane == 0) {
+                    ops[k >> 4] = (uint32_t)opacc;
+                    ops[(k >> 4) + 1] = (uint32_t)(opacc >> 32);
+                }
+                k += 32;
+                opacc = 0;
+                fill = 0;
+            }
+        }
+    };
+    auto emit = [&](uint32_t mv) { emit_run(mv, 1); };
+
+    // Lane q looks at cell (i - q, j - q): the cells of a diagonal run are evaluated together, and
+    // one round of LDS reads advances the walk by the whole run plus the move that ends it.
+    while (i > 0 && j > 0) {
+        const int ii = i - lane, jj = j - lane;
+        bool ok = ii >= 1 && jj >= 1;
+        uint32_t rcq = 0, ruq = 0, rlq = 0;
+        if (ok) {
+            rcq = peek(ii, jj, ok);
+            ruq = peek(ii - 1, jj, ok);
+            rlq = peek(ii, jj - 1, ok);
+        }
+        const uint64_t okmask = __ballot(ok);
+        if (!(okmask & 1ull)) {
+            // the walk's own cell is not staged: stage what it needs (uniform path), then look again
+            (void)residue(i, j);
+            (void)residue(i - 1, j);
+            (void)residue(i, j - 1);
+            continue;
+        }
+        const bool above_up = ((rcq - ruq) & MASK) != 0;    // cur > up
+        const bool above_left = ((rcq - rlq) & MASK) != 0;  // cur > left
+        const bool is_diag = ok && above_up && above_left;
+        const uint32_t mvq = (!above_left && above_up) ? BA_MV_LEFT : BA_MV_UP;
+        const uint64_t dmask = __ballot(is_diag);
+        const uint32_t run = dmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~dmask);
+        emit_run(BA_MV_DIAG, run);
+        i -= (int)run;
+        j -= (int)run;
+        if (run < 64 && ((okmask >> run) & 1ull)) {
+            // lane `run` sits on the cell the run ends at and knows its (non-diagonal) move
+            const uint32_t mv = (uint32_t)__builtin_amdgcn_readlane((int)mvq, (int)run);
+            emit(mv);
+            if (mv == BA_MV_LEFT)
+                --j;
+            else
+                --i;
         }
     }
     // borders (align.go:92-100; align_pair.go:110-113, 158-159, 187-188)
-    if (!left_free)
-        while (i > 0) {
-            w1.put(sym(0, P.s1, n, i - 1, base1));
-            w2.put(gs);
-            --i;
-        }
-    if (!top_free)
-        while (j > 0) {
-            w1.put(gs);
-            w2.put(sym(1, P.s2, m, j - 1, base2));
-            --j;
-        }
-    w1.finish();
-    w2.finish();
+    if (!left_free && i > 0) emit_run(BA_MV_UP, (uint32_t)i);
+    if (!top_free && j > 0) emit_run(BA_MV_LEFT, (uint32_t)j);
     if (lane == 0) {
-        const uint64_t len = (uint64_t)w1.length();
-        *P.t_off = cap - len;
-        *P.t_len = len;
+        if (fill > 0) ops[k >> 4] = (uint32_t)opacc;
+        if (fill > 16) ops[(k >> 4) + 1] = (uint32_t)(opacc >> 32);
+        P.walk[2] = k + fill;  // trace length
+    }
+}
+
+__global__ void __launch_bounds__(1024) ba_long_expand_kernel(BaLongParams P)
+{
+    __shared__ uint32_t wsum1[16], wsum2[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t L = P.walk[2];
+    const uint64_t cap = (uint64_t)P.n + (uint64_t)P.m;
+    const uint32_t gs = P.gap_symbol;
+    uint32_t i0 = P.walk[0], j0 = P.walk[1];  // row / column of the first move of the current round
+    for (uint32_t base = 0; base < L; base += 16 * 1024) {
+        const uint32_t first = base + 16u * tid;  // this thread's 16 moves
+        const uint32_t w = first < L ? P.ops[first >> 4] : 0u;
+        const uint32_t cnt = first < L ? min(16u, L - first) : 0u;
+        const uint32_t valid = cnt == 16 ? 0xffffffffu : ((1u << (2 * cnt)) - 1u);
+        const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;  // code 0 up, 1 left, 2 diagonal
+        const uint32_t is_left = lo & ~hi & valid & 0x55555555u;
+        const uint32_t is_up = ~lo & ~hi & valid & 0x55555555u;
+        const uint32_t c1 = cnt - __popc(is_left);  // moves that consume a symbol of s1
+        const uint32_t c2 = cnt - __popc(is_up);    // ... of s2
+        // block-wide exclusive prefix sums of c1, c2
+        uint32_t p1 = c1, p2 = c2;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t a = __shfl_up(p1, d), b = __shfl_up(p2, d);
+            if (lane >= d) {
+                p1 += a;
+                p2 += b;
+            }
+        }
+        if (lane == 63) {
+            wsum1[wave] = p1;
+            wsum2[wave] = p2;
+        }
+        __syncthreads();
+        uint32_t off1 = 0, off2 = 0, tot1 = 0, tot2 = 0;
+        for (int q = 0; q < 16; ++q) {
+            if (q < wave) {
+                off1 += wsum1[q];
+                off2 += wsum2[q];
+            }
+            tot1 += wsum1[q];
+            tot2 += wsum2[q];
+        }
+        uint32_t ii = i0 - (off1 + p1 - c1), jj = j0 - (off2 + p2 - c2);  // cell of my first move
+        for (uint32_t q = 0; q < cnt; ++q) {
+            const uint32_t mv = (w >> (2 * q)) & 3u;
+            const uint64_t pos = cap - 1 - (uint64_t)(first + q);
+            P.t1[pos] = mv == BA_MV_LEFT ? (uint8_t)gs : P.s1[ii - 1];
+            P.t2[pos] = mv == BA_MV_UP ? (uint8_t)gs : P.s2[jj - 1];
+            ii -= (mv != BA_MV_LEFT);
+            jj -= (mv != BA_MV_UP);
+        }
+        i0 -= tot1;
+        j0 -= tot2;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *P.t_off = cap - L;
+        *P.t_len = L;
     }
 }
 
@@ -377,7 +482,10 @@ static hipError_t launch_long(const BaLongParams &P, hipStream_t st)
     hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K>), dim3(P.strips), dim3(64), 0, st, P);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ba_long_trace_kernel<MODE, T, K>), dim3(1), dim3(64), 0, st, P);
+    hipLaunchKernelGGL((ba_long_walk_kernel<MODE, T, K>), dim3(1), dim3(64), 0, st, P);
+    e = hipGetLastError();
+    if (e != hipSuccess || P.score_only) return e;
+    hipLaunchKernelGGL(ba_long_expand_kernel, dim3(1), dim3(1024), 0, st, P);
     return hipGetLastError();
 }
 
