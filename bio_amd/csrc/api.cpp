@@ -92,6 +92,7 @@ struct bioalign_plan {
     uint32_t *d_s1w = nullptr, *d_s2w = nullptr;
     int32_t *d_hb = nullptr;
     uint32_t *d_dir = nullptr;
+    void *d_rec = nullptr;  // move records of the linear-gap walk (16 bytes per 16 trace columns)
     BaLocalBest *d_best = nullptr;
     uint64_t ws_bytes = 0;
     // timing hooks: a fixed pool of event pairs, one pair per DP launch since the last reset
@@ -296,8 +297,11 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     uint64_t budget = env_u64("BIOALIGN_WORKSPACE_BYTES", 96ull << 30);
     pl->bundles.clear();
     pl->chunks.clear();
-    uint64_t o_s1w = 0, o_s2w = 0, o_hb = 0, o_dir = 0;
-    uint64_t m_s1w = 0, m_s2w = 0, m_hb = 0, m_dir = 0;
+    uint64_t o_s1w = 0, o_s2w = 0, o_hb = 0, o_dir = 0, o_rec = 0;
+    uint64_t m_s1w = 0, m_s2w = 0, m_hb = 0, m_dir = 0, m_rec = 0;
+    // linear gaps: the walk records its moves and a second kernel expands them (kernels.hip); BIOALIGN_TRACE_BYTES=1
+    // keeps the older walk that writes the bytes itself
+    const bool use_rec = !pl->affine && !pl->score_only && env_u64("BIOALIGN_TRACE_BYTES", 0) == 0;
     uint32_t chunk_begin = 0;
     for (uint64_t q = 0; q < N;) {
         const uint32_t n = len1[perm[q]], m = len2[perm[q]];
@@ -310,11 +314,13 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         const uint64_t sz_hb = pl->affine ? 2 * (uint64_t)m * 64 * 2 : 2 * (uint64_t)((m + 3) / 4 + 1) * 64;
         const uint64_t sz_dir = pl->affine ? strips * ((m + cpw - 1) / cpw) * 64 * 4
                                            : strips * (uint64_t)((m + 3) / 4) * 64 * chw;
-        const uint64_t after = (o_s1w + sz_s1w + o_s2w + sz_s2w + o_hb + sz_hb + o_dir + sz_dir) * 4;
+        const uint64_t rec_cap = ((uint64_t)n + m) / 16 + 1;
+        const uint64_t sz_rec = use_rec ? rec_cap * 64 : 0;  // records of 16 bytes
+        const uint64_t after = (o_s1w + sz_s1w + o_s2w + sz_s2w + o_hb + sz_hb + o_dir + sz_dir) * 4 + (o_rec + sz_rec) * 16;
         if (after > budget && pl->bundles.size() > chunk_begin) {
             pl->chunks.push_back({chunk_begin, (uint32_t)pl->bundles.size()});
             chunk_begin = (uint32_t)pl->bundles.size();
-            o_s1w = o_s2w = o_hb = o_dir = 0;
+            o_s1w = o_s2w = o_hb = o_dir = o_rec = 0;
         }
         BaBundle B;
         B.n = n;
@@ -325,15 +331,20 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         B.s2w_off = o_s2w;
         B.hb_off = o_hb;
         B.dir_off = o_dir;
+        B.rec_off = o_rec;
+        B.rec_cap = (uint32_t)rec_cap;
+        B.pad = 0;
         pl->bundles.push_back(B);
         o_s1w += sz_s1w;
         o_s2w += sz_s2w;
         o_hb += sz_hb;
         o_dir += sz_dir;
+        o_rec += sz_rec;
         m_s1w = std::max(m_s1w, o_s1w);
         m_s2w = std::max(m_s2w, o_s2w);
         m_hb = std::max(m_hb, o_hb);
         m_dir = std::max(m_dir, o_dir);
+        m_rec = std::max(m_rec, o_rec);
         q = e;
     }
     if (pl->bundles.size() > chunk_begin) pl->chunks.push_back({chunk_begin, (uint32_t)pl->bundles.size()});
@@ -378,6 +389,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     if ((rc = dev_alloc(pl, (void **)&pl->d_s2w, m_s2w * 4))) return rc;
     if ((rc = dev_alloc(pl, (void **)&pl->d_hb, m_hb * 4))) return rc;
     if ((rc = dev_alloc(pl, (void **)&pl->d_dir, m_dir * 4))) return rc;
+    if (use_rec && (rc = dev_alloc(pl, &pl->d_rec, m_rec * 16))) return rc;
     if ((rc = dev_alloc(pl, (void **)&pl->d_best, (N ? N : 1) * sizeof(BaLocalBest)))) return rc;
     if (pl->affine) {
         // Few bundles cannot fill 1024 SIMDs with one wavefront each: run the strips of a bundle
@@ -556,6 +568,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             tr.t2 = d_t2;
             tr.t_off = d_t_off;
             tr.t_len = d_t_len;
+            tr.rec = pl->d_rec;
             if (pl->affine)
                 HIP_TRY(ctx, ba_launch_trace_affine(tr, pl->mode, pl->R, ts));
             else

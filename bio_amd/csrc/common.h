@@ -27,6 +27,9 @@ struct BaBundle {
     uint64_t s2w_off;  // dword offset of the bundle's lane-interleaved s2 words (raw bytes)
     uint64_t hb_off;   // dword offset of the bundle's boundary-delta words (strip hand-over row)
     uint64_t dir_off;  // dword offset of the bundle's direction words
+    uint64_t rec_off;  // record offset of the bundle's move records (lane l: rec_off + l * rec_cap)
+    uint32_t rec_cap;  // records per pair = (n + m) / 16 + 1
+    uint32_t pad;
 };
 
 // end cell of a local alignment, found by the DP kernel
@@ -82,8 +85,7 @@ struct BaTraceParams {
     int64_t *scores;
     uint8_t *t1, *t2;
     uint64_t *t_off, *t_len;
-    uint32_t *ops;                 // 2-bit move codes of the walk, 16 per dword, last column first
-    uint32_t *walk;                // [0], [1]: end cell (i, j); [2]: number of moves
+    void *rec;             // move records (linear-gap walk + expansion), or null: the walk writes bytes itself
 };
 
 // ----------------------------------------------------------------------------

@@ -377,7 +377,19 @@ struct BaTraceGeom {
     static constexpr int WORDS = 2 * BW;       // LDS words per lane (two bands)
 };
 
-template <int MODE, int R, int K>
+// One record of the walk: 16 moves, 2 bits each (first move in the low bits), and the cell
+// the first of them starts from.
+struct BaMoveRec {
+    uint32_t ops, i, j, count;
+};
+enum { BA_MV_UP = 0, BA_MV_LEFT = 1, BA_MV_DIAG = 2 };
+
+// OPS == false: the walk writes the two gapped byte strings itself (one lane = one pair,
+//               16-byte shift registers).
+// OPS == true : the walk only records its moves (BaMoveRec per 16 moves); ba_expand_kernel
+//               turns them into bytes with one thread per record -- no symbol load, no byte
+//               shuffling and no scattered store left on the walk's critical path.
+template <int MODE, int R, int K, bool OPS>
 __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
 {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -386,17 +398,6 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
-    // score table (as the caller gave it) and the byte -> code maps, shared by the block
-    const int tbl_words = (P.na * P.nb + 3) & ~3;
-    int32_t *tbl = reinterpret_cast<int32_t *>(lds);
-    uint8_t *code1 = reinterpret_cast<uint8_t *>(lds + tbl_words);
-    uint8_t *code2 = code1 + 256;
-    for (int i = threadIdx.x; i < P.na * P.nb; i += blockDim.x) tbl[i] = P.table[i];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        code1[i] = P.code1[i];
-        code2[i] = P.code2[i];
-    }
-    __syncthreads();
     const uint32_t b_idx = P.bundle_begin + blockIdx.x * waves + wave;
     if (b_idx >= P.bundle_end) return;
     const BaBundle B = P.bundles[b_idx];
@@ -408,7 +409,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     const uint64_t o1 = live ? P.s1_off[p] : 0, o2 = live ? P.s2_off[p] : 0;
     const int cgs = (m + 3) / 4;
     const int front = ((n + R - 1) / R) * R - n;
-    uint32_t *band = lds + tbl_words + 128 + (size_t)wave * (G::WORDS * 64) + lane;  // band[word * 64]
+    uint32_t *band = lds + (size_t)wave * (G::WORDS * 64) + lane;  // band[word * 64]
 
     constexpr bool top_free = (MODE == BA_LOCAL || MODE == BA_FITTING);
     constexpr bool left_free = (MODE == BA_LOCAL || MODE == BA_OVERLAP);
@@ -494,7 +495,26 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     w1.init(P.t1, slot + cap);
     w2.init(P.t2, slot + cap);
     const uint32_t gs = P.gap_symbol;
-    const int wbias = (MODE == BA_LOCAL) ? 0 : 2 * g;
+    // OPS: the record being filled
+    BaMoveRec *recs = reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap;
+    uint32_t opw = 0, kq = 0, rec_i = 0, rec_j = 0;
+    auto record = [&](uint32_t mv) {  // the move leaves cell (i, j)
+        if ((kq & 15u) == 0) {
+            rec_i = (uint32_t)i;
+            rec_j = (uint32_t)j;
+        }
+        opw |= mv << ((kq & 15u) * 2);
+        ++kq;
+        if ((kq & 15u) == 0) {
+            BaMoveRec rr;
+            rr.ops = opw;
+            rr.i = rec_i;
+            rr.j = rec_j;
+            rr.count = 16;
+            recs[(kq >> 4) - 1] = rr;
+            opw = 0;
+        }
+    };
     const int b_top = (MODE == BA_FITTING) ? g : 0;   // Hs(0, j) = b_top * j
     const int b_left = (MODE == BA_OVERLAP) ? g : 0;  // Hs(i, 0) = b_left * i
 
@@ -536,7 +556,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
             last_rb = rb;
         }
         const bool need_above = (f == 0) && (iu > 1);  // uniform: row iu-1 lies in row block rb-1
-        const uint32_t x_row = sym1(iu);                // s1[iu-1] of every lane
+        const uint32_t x_row = OPS ? 0u : sym1(iu);     // s1[iu-1] of every lane
         // lanes take their left moves, then leave the row by an up or a diagonal move
         while (true) {
             const bool act = !done && i == iu;
@@ -546,8 +566,12 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
                     if (left_free) {
                         done = true;
                     } else {  // left border of global / fitting: forced up move, Hs(i-1, 0) = 0
-                        w1.put(x_row);
-                        w2.put(gs);
+                        if (OPS) {
+                            record(BA_MV_UP);
+                        } else {
+                            w1.put(x_row);
+                            w2.put(gs);
+                        }
                         --i;
                         cur = 0;
                     }
@@ -582,18 +606,37 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
                         r_diag = (Bw >> shu) & MASK;
                     }
                     const uint32_t r_left = (Bw >> (f * K)) & MASK;
-                    const int up = (iu == 1) ? b_top * j : neighbour(cur, r_up);
-                    const int left = (j == 1) ? b_left * iu : neighbour(cur, r_left);
-                    const int diag = (iu == 1) ? b_top * (j - 1) : (j == 1) ? b_left * (iu - 1) : neighbour(up, r_diag);
-                    const uint32_t x = x_row;
-                    const uint32_t y = sym2(j);
-                    const int w = tbl[(int)code1[x] * P.nb + (int)code2[y]] + wbias;
-                    const int d = diag + w;
-                    const int mx = (MODE == BA_LOCAL) ? max(up, left) - g : max(up, left);
-                    const int mv = d > mx ? 2 : (left > up ? 1 : 0);  // 0 up, 1 left, 2 diagonal
-                    cur = d > mx ? diag : (left > up ? left : up);
-                    w1.put(mv == 1 ? gs : x);
-                    w2.put(mv == 0 ? gs : y);
+                    int mv;  // 0 up, 1 left, 2 diagonal
+                    if (MODE == BA_LOCAL) {
+                        // cur = max(0, up - g, left - g, diag + w) > 0 here, skip-prefix first, then up > left >
+                        // diagonal (align.go:186-202): the cell came through the diagonal iff it is above both
+                        // up - g and left - g.  Exact neighbours follow from the residues; no score table needed.
+                        const int up = (iu == 1) ? 0 : neighbour(cur, r_up);
+                        const int left = (j == 1) ? 0 : neighbour(cur, r_left);
+                        const int diag = (iu == 1 || j == 1) ? 0 : neighbour(up, r_diag);
+                        const bool from_up = cur == up - g, from_left = cur == left - g;
+                        mv = (!from_up && !from_left) ? 2 : (from_left && !from_up) ? 1 : 0;
+                        cur = mv == 2 ? diag : mv == 1 ? left : up;
+                    } else {
+                        // Biased space: cur = max3(up, left, diag + w) with 0 <= cur - up, cur - left < 2^K, so
+                        //   diagonal <=> cur > up and cur > left;  left <=> cur == left and cur > up;  else up
+                        // (align.go:105-116) -- and "cur > x" is "residues differ".  No score, no table, no
+                        // symbol on the decision path; `cur` only carries the current cell's residue.
+                        const uint32_t rc = (uint32_t)cur & MASK;
+                        const uint32_t ru = (iu == 1) ? (uint32_t)(b_top * j) & MASK : r_up;
+                        const uint32_t rl = (j == 1) ? (uint32_t)(b_left * iu) & MASK : r_left;
+                        const uint32_t rd = (iu == 1) ? (uint32_t)(b_top * (j - 1)) & MASK
+                                                      : (j == 1) ? (uint32_t)(b_left * (iu - 1)) & MASK : r_diag;
+                        const bool above_up = rc != ru, above_left = rc != rl;
+                        mv = (above_up && above_left) ? 2 : (above_up && !above_left) ? 1 : 0;
+                        cur = (int)(mv == 2 ? rd : mv == 1 ? rl : ru);
+                    }
+                    if (OPS) {
+                        record((uint32_t)mv);
+                    } else {
+                        w1.put(mv == 1 ? gs : x_row);
+                        w2.put(mv == 0 ? gs : sym2(j));
+                    }
                     i -= (mv != 1);
                     j -= (mv != 0);
                 }
@@ -603,17 +646,91 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     // row 0: global / overlap walk left along the top border; local / fitting stop there
     if (!done && !top_free) {
         while (j > 0) {
-            w1.put(gs);
-            w2.put(sym2(j));
+            if (OPS) {
+                record(BA_MV_LEFT);
+            } else {
+                w1.put(gs);
+                w2.put(sym2(j));
+            }
             --j;
         }
     }
-    if (live) {
+    if (!live) return;
+    if (OPS) {
+        if (kq & 15u) {
+            BaMoveRec rr;
+            rr.ops = opw;
+            rr.i = rec_i;
+            rr.j = rec_j;
+            rr.count = kq & 15u;
+            recs[kq >> 4] = rr;
+        }
+        // Where the trace ends inside the pair's slot: at the slot's end, or -- whenever the slot
+        // has the room -- at the 16-byte boundary just below it, so that every full record of
+        // the expansion is one aligned 16-byte store.
+        const uint64_t len = kq;
+        const uint64_t mis = ((uint64_t)P.t1 + slot + cap) & 15u;
+        const uint64_t end = (mis + len <= cap) ? slot + cap - mis : slot + cap;
+        P.t_off[p] = end - len;
+        P.t_len[p] = len;
+    } else {
         w1.finish();
         w2.finish();
         const uint64_t len = (uint64_t)w1.length();
         P.t_off[p] = slot + cap - len;
         P.t_len[p] = len;
+    }
+}
+
+// Expansion of the walk's records into the two gapped byte strings (align.go:126-143, 224-248;
+// align_pair.go:197-216).  One block per bundle, 16 threads per pair, one record (16 trace
+// columns) per thread and round: the symbols a record needs are two short runs of s1 and s2.
+__global__ void __launch_bounds__(1024) ba_expand_kernel(BaTraceParams P)
+{
+    const uint32_t b_idx = P.bundle_begin + blockIdx.x;
+    if (b_idx >= P.bundle_end) return;
+    const BaBundle B = P.bundles[b_idx];
+    const uint32_t q = threadIdx.x >> 4, g16 = threadIdx.x & 15;
+    if (q >= B.count) return;
+    const uint32_t p = P.perm[B.first + q];
+    const uint64_t len = P.t_len[p];
+    const uint64_t end = P.t_off[p] + len;
+    const uint8_t *s1 = P.s1 + P.s1_off[p];
+    const uint8_t *s2 = P.s2 + P.s2_off[p];
+    const BaMoveRec *recs = reinterpret_cast<const BaMoveRec *>(P.rec) + B.rec_off + (size_t)q * B.rec_cap;
+    const uint32_t nrec = (uint32_t)((len + 15) / 16);
+    const uint32_t gs = P.gap_symbol;
+    const bool al1 = (((uint64_t)P.t1 + end) & 15u) == 0, al2 = (((uint64_t)P.t2 + end) & 15u) == 0;
+    for (uint32_t r = g16; r < nrec; r += 16) {
+        const BaMoveRec rr = recs[r];
+        const uint32_t lo = rr.ops & 0x55555555u, hi = (rr.ops >> 1) & 0x55555555u;
+        const uint32_t is_left = lo & ~hi, is_up = ~lo & ~hi & 0x55555555u;
+        // code k sits in bits 2k: symbols consumed before code k = k - (lefts | ups below bit 2k)
+        uint32_t a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t below = (1u << (2 * k)) - 1u;
+            const uint32_t mv = (rr.ops >> (2 * k)) & 3u;
+            const uint32_t ii = rr.i - (k - __popc(is_left & below));
+            const uint32_t jj = rr.j - (k - __popc(is_up & below));
+            const bool in = (uint32_t)k < rr.count;
+            const uint32_t x = (!in || mv == BA_MV_LEFT) ? gs : (uint32_t)s1[ii - 1];
+            const uint32_t y = (!in || mv == BA_MV_UP) ? gs : (uint32_t)s2[jj - 1];
+            // code k is trace column end - 16r - 1 - k: byte 15 - k of the record's 16-byte chunk
+            a[(15 - k) >> 2] |= x << (((15 - k) & 3) * 8);
+            b[(15 - k) >> 2] |= y << (((15 - k) & 3) * 8);
+        }
+        const uint64_t chunk = end - 16ull * (r + 1);
+        if (rr.count == 16 && al1) {
+            *reinterpret_cast<uint4 *>(P.t1 + chunk) = make_uint4(a[0], a[1], a[2], a[3]);
+        } else {
+            for (uint32_t k = 0; k < rr.count; ++k) P.t1[chunk + 15 - k] = (uint8_t)(a[(15 - k) >> 2] >> (((15 - k) & 3) * 8));
+        }
+        if (rr.count == 16 && al2) {
+            *reinterpret_cast<uint4 *>(P.t2 + chunk) = make_uint4(b[0], b[1], b[2], b[3]);
+        } else {
+            for (uint32_t k = 0; k < rr.count; ++k) P.t2[chunk + 15 - k] = (uint8_t)(b[(15 - k) >> 2] >> (((15 - k) & 3) * 8));
+        }
     }
 }
 
@@ -670,10 +787,11 @@ extern "C" hipError_t ba_launch_dp_linear(const BaDpParams &P, int mode, int R, 
 
 extern "C" size_t ba_trace_linear_lds_bytes(int na, int nb, int R, int K, int waves)
 {
-    const int tbl = (na * nb + 3) & ~3;
+    (void)na;
+    (void)nb;
     const int F = 32 / K;
     const int words = 2 * (F / 4 + 2) * 4;  // BaTraceGeom::WORDS
-    return ((size_t)tbl + 128 + (size_t)waves * words * 64) * 4;
+    return ((size_t)waves * words * 64) * 4;
 }
 
 template <int MODE, int R, int K>
@@ -683,7 +801,14 @@ static hipError_t launch_trace(const BaTraceParams &P, hipStream_t st)
     const uint32_t nbundles = P.bundle_end - P.bundle_begin;
     const uint32_t blocks = (nbundles + waves - 1) / waves;
     const size_t lds = ba_trace_linear_lds_bytes(P.na, P.nb, R, K, waves);
-    hipLaunchKernelGGL((ba_trace_linear_kernel<MODE, R, K>), dim3(blocks), dim3(waves * 64), lds, st, P);
+    if (P.rec && !P.score_only) {
+        hipLaunchKernelGGL((ba_trace_linear_kernel<MODE, R, K, true>), dim3(blocks), dim3(waves * 64), lds, st, P);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(ba_expand_kernel, dim3(nbundles), dim3(1024), 0, st, P);
+    } else {
+        hipLaunchKernelGGL((ba_trace_linear_kernel<MODE, R, K, false>), dim3(blocks), dim3(waves * 64), lds, st, P);
+    }
     return hipGetLastError();
 }
 

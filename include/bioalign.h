@@ -93,8 +93,10 @@ typedef struct {
  * t1 and t2 each have capacity s1_off[n_pairs] + s2_off[n_pairs] bytes: pair p
  * owns the slot [s1_off[p]+s2_off[p], s1_off[p+1]+s2_off[p+1]) -- the longest
  * possible trace -- and its traces are the t_len[p] bytes starting at t_off[p]
- * inside that slot (right aligned: the traceback writes them back to front, so
- * no reversal pass is needed).  t_len[p] == 0 is the reference's nil trace.
+ * inside that slot (towards the slot's end: the traceback produces them back to
+ * front, so no reversal pass is needed; read them through t_off / t_len, the
+ * exact placement inside the slot is the library's).  t_len[p] == 0 is the
+ * reference's nil trace.
  * With BIOALIGN_SCORE_ONLY, t1/t2/t_off/t_len may be NULL.
  */
 typedef struct {
