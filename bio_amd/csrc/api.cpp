@@ -314,7 +314,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         const uint64_t sz_hb = pl->affine ? 2 * (uint64_t)m * 64 * 2 : 2 * (uint64_t)((m + 3) / 4 + 1) * 64;
         const uint64_t sz_dir = pl->affine ? strips * ((m + cpw - 1) / cpw) * 64 * 4
                                            : strips * (uint64_t)((m + 3) / 4) * 64 * chw;
-        const uint64_t rec_cap = ((uint64_t)n + m) / 16 + 1;
+        const uint64_t rec_cap = ((uint64_t)n + m) / 16 + 2;  // header + ceil((n + m) / 16) records
         const uint64_t sz_rec = use_rec ? rec_cap * 64 : 0;  // records of 16 bytes
         const uint64_t after = (o_s1w + sz_s1w + o_s2w + sz_s2w + o_hb + sz_hb + o_dir + sz_dir) * 4 + (o_rec + sz_rec) * 16;
         if (after > budget && pl->bundles.size() > chunk_begin) {

@@ -28,7 +28,7 @@ struct BaBundle {
     uint64_t hb_off;   // dword offset of the bundle's boundary-delta words (strip hand-over row)
     uint64_t dir_off;  // dword offset of the bundle's direction words
     uint64_t rec_off;  // record offset of the bundle's move records (lane l: rec_off + l * rec_cap)
-    uint32_t rec_cap;  // records per pair = (n + m) / 16 + 1
+    uint32_t rec_cap;  // records per pair = header + ceil((n + m) / 16)
     uint32_t pad;
 };
 

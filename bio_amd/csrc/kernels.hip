@@ -438,14 +438,21 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
                     const int t = row - 1 + front;
                     const int rb = t / F, sh = (t % F) * K;
                     int v = 0;
-                    for (int cg = 0; cg < cgs && j == 0; ++cg) {
-                        const uint4 q = block_words(rb, cg);
-                        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+                    // eight column groups per round: the loads of a round are all in flight together
+                    for (int cg0 = 0; cg0 < cgs && j == 0; cg0 += 8) {
+                        uint4 q[8];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const uint32_t rho = (wd[c] >> sh) & MASK;
-                            v = v + (int)((rho - (uint32_t)v + (uint32_t)off) & MASK) - off;
-                            if (j == 0 && cg * 4 + c < m && v == bb.score) j = cg * 4 + c + 1;
+                        for (int u = 0; u < 8; ++u) q[u] = block_words(rb, min(cg0 + u, cgs - 1));
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int cg = cg0 + u;
+                            const uint32_t wd[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const uint32_t rho = (wd[c] >> sh) & MASK;
+                                v = v + (int)((rho - (uint32_t)v + (uint32_t)off) & MASK) - off;
+                                if (j == 0 && cg * 4 + c < m && v == bb.score) j = cg * 4 + c + 1;
+                            }
                         }
                     }
                     i = row;
@@ -496,7 +503,9 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     w2.init(P.t2, slot + cap);
     const uint32_t gs = P.gap_symbol;
     // OPS: the record being filled
-    BaMoveRec *recs = reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap;
+    // (record 0 of a pair is a header for the expansion: trace length and end, so that it need not chase
+    // perm -> t_len / t_off first)
+    BaMoveRec *recs = reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap + 1;
     uint32_t opw = 0, kq = 0, rec_i = 0, rec_j = 0;
     auto record = [&](uint32_t mv) {  // the move leaves cell (i, j)
         if ((kq & 15u) == 0) {
@@ -673,6 +682,12 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
         const uint64_t end = (mis + len <= cap) ? slot + cap - mis : slot + cap;
         P.t_off[p] = end - len;
         P.t_len[p] = len;
+        BaMoveRec hd;
+        hd.ops = (uint32_t)len;
+        hd.i = (uint32_t)end;
+        hd.j = (uint32_t)(end >> 32);
+        hd.count = p;
+        recs[-1] = hd;
     } else {
         w1.finish();
         w2.finish();
@@ -685,37 +700,59 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
 // Expansion of the walk's records into the two gapped byte strings (align.go:126-143, 224-248;
 // align_pair.go:197-216).  One block per bundle, 16 threads per pair, one record (16 trace
 // columns) per thread and round: the symbols a record needs are two short runs of s1 and s2.
-__global__ void __launch_bounds__(1024) ba_expand_kernel(BaTraceParams P)
+#define BA_EXPAND_TPP 8  // threads per pair
+__global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_expand_kernel(BaTraceParams P)
 {
+    // per thread: the (at most 16, unaligned) bytes of s1 and of s2 its record consumes, as 5 aligned dwords each
+    __shared__ uint32_t stage[64 * BA_EXPAND_TPP * 10];
     const uint32_t b_idx = P.bundle_begin + blockIdx.x;
     if (b_idx >= P.bundle_end) return;
     const BaBundle B = P.bundles[b_idx];
-    const uint32_t q = threadIdx.x >> 4, g16 = threadIdx.x & 15;
+    const uint32_t q = threadIdx.x / BA_EXPAND_TPP, g16 = threadIdx.x % BA_EXPAND_TPP;
     if (q >= B.count) return;
-    const uint32_t p = P.perm[B.first + q];
-    const uint64_t len = P.t_len[p];
-    const uint64_t end = P.t_off[p] + len;
+    const BaMoveRec *recs = reinterpret_cast<const BaMoveRec *>(P.rec) + B.rec_off + (size_t)q * B.rec_cap + 1;
+    const BaMoveRec hd = recs[-1];
+    const uint32_t p = hd.count;
+    const uint64_t len = hd.ops;
+    const uint64_t end = (uint64_t)hd.i | ((uint64_t)hd.j << 32);
     const uint8_t *s1 = P.s1 + P.s1_off[p];
     const uint8_t *s2 = P.s2 + P.s2_off[p];
-    const BaMoveRec *recs = reinterpret_cast<const BaMoveRec *>(P.rec) + B.rec_off + (size_t)q * B.rec_cap;
     const uint32_t nrec = (uint32_t)((len + 15) / 16);
     const uint32_t gs = P.gap_symbol;
     const bool al1 = (((uint64_t)P.t1 + end) & 15u) == 0, al2 = (((uint64_t)P.t2 + end) & 15u) == 0;
-    for (uint32_t r = g16; r < nrec; r += 16) {
+    uint32_t *st1 = stage + threadIdx.x * 10, *st2 = st1 + 5;
+    // stages src[lo .. lo+15] (clamped to the sequence's own dwords); returns the staged bytes, index = position - lo + shift
+    auto stage_in = [&](uint32_t *dst, const uint8_t *src, uint32_t lo, uint32_t seq_len) -> const uint8_t * {
+        const uint64_t a = (uint64_t)(src + lo), a0 = a & ~(uint64_t)3;
+        const uint64_t last = ((uint64_t)src + seq_len - 1) & ~(uint64_t)3;
+        uint32_t v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = *reinterpret_cast<const uint32_t *>(min(a0 + 4 * k, last));
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dst[k] = v[k];
+        return reinterpret_cast<const uint8_t *>(dst) + (a - a0);
+    };
+    for (uint32_t r = g16; r < nrec; r += BA_EXPAND_TPP) {
         const BaMoveRec rr = recs[r];
+        const uint32_t valid = rr.count >= 16 ? 0xffffffffu : ((1u << (2 * rr.count)) - 1u);
         const uint32_t lo = rr.ops & 0x55555555u, hi = (rr.ops >> 1) & 0x55555555u;
-        const uint32_t is_left = lo & ~hi, is_up = ~lo & ~hi & 0x55555555u;
-        // code k sits in bits 2k: symbols consumed before code k = k - (lefts | ups below bit 2k)
+        const uint32_t is_left = lo & ~hi & valid, is_up = ~lo & ~hi & 0x55555555u & valid;
+        const uint32_t c1 = rr.count - __popc(is_left), c2 = rr.count - __popc(is_up);  // symbols consumed
+        // the record consumes s1[i - c1 .. i - 1] and s2[j - c2 .. j - 1] (0-based), from the top down
+        const uint8_t *b1 = reinterpret_cast<const uint8_t *>(st1), *b2 = reinterpret_cast<const uint8_t *>(st2);
+        if (c1) b1 = stage_in(st1, s1, rr.i - c1, B.n);
+        if (c2) b2 = stage_in(st2, s2, rr.j - c2, B.m);
         uint32_t a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const uint32_t below = (1u << (2 * k)) - 1u;
             const uint32_t mv = (rr.ops >> (2 * k)) & 3u;
-            const uint32_t ii = rr.i - (k - __popc(is_left & below));
-            const uint32_t jj = rr.j - (k - __popc(is_up & below));
+            // symbols consumed before code k = k - (lefts | ups below it); the staged run starts at i - c1
+            const uint32_t u1 = c1 - 1 - (k - __popc(is_left & below));
+            const uint32_t u2 = c2 - 1 - (k - __popc(is_up & below));
             const bool in = (uint32_t)k < rr.count;
-            const uint32_t x = (!in || mv == BA_MV_LEFT) ? gs : (uint32_t)s1[ii - 1];
-            const uint32_t y = (!in || mv == BA_MV_UP) ? gs : (uint32_t)s2[jj - 1];
+            const uint32_t x = (!in || mv == BA_MV_LEFT) ? gs : (uint32_t)b1[u1];
+            const uint32_t y = (!in || mv == BA_MV_UP) ? gs : (uint32_t)b2[u2];
             // code k is trace column end - 16r - 1 - k: byte 15 - k of the record's 16-byte chunk
             a[(15 - k) >> 2] |= x << (((15 - k) & 3) * 8);
             b[(15 - k) >> 2] |= y << (((15 - k) & 3) * 8);
@@ -805,7 +842,7 @@ static hipError_t launch_trace(const BaTraceParams &P, hipStream_t st)
         hipLaunchKernelGGL((ba_trace_linear_kernel<MODE, R, K, true>), dim3(blocks), dim3(waves * 64), lds, st, P);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(ba_expand_kernel, dim3(nbundles), dim3(1024), 0, st, P);
+        hipLaunchKernelGGL(ba_expand_kernel, dim3(nbundles), dim3(64 * BA_EXPAND_TPP), 0, st, P);
     } else {
         hipLaunchKernelGGL((ba_trace_linear_kernel<MODE, R, K, false>), dim3(blocks), dim3(waves * 64), lds, st, P);
     }
