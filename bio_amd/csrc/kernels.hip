@@ -720,7 +720,7 @@ __global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_expand_kernel(BaTracePa
     const uint32_t nrec = (uint32_t)((len + 15) / 16);
     const uint32_t gs = P.gap_symbol;
     const bool al1 = (((uint64_t)P.t1 + end) & 15u) == 0, al2 = (((uint64_t)P.t2 + end) & 15u) == 0;
-    uint32_t *st1 = stage + threadIdx.x * 10, *st2 = st1 + 5;
+    uint32_t *st1 = stage + threadIdx.x * 5, *st2 = stage + 64 * BA_EXPAND_TPP * 5 + threadIdx.x * 5;  // stride 5: no bank conflicts
     // stages src[lo .. lo+15] (clamped to the sequence's own dwords); returns the staged bytes, index = position - lo + shift
     auto stage_in = [&](uint32_t *dst, const uint8_t *src, uint32_t lo, uint32_t seq_len) -> const uint8_t * {
         const uint64_t a = (uint64_t)(src + lo), a0 = a & ~(uint64_t)3;
@@ -743,16 +743,16 @@ __global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_expand_kernel(BaTracePa
         if (c1) b1 = stage_in(st1, s1, rr.i - c1, B.n);
         if (c2) b2 = stage_in(st2, s2, rr.j - c2, B.m);
         uint32_t a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+        // codes beyond rr.count are 0 (= up): they only ever produce bytes that are not stored
+        int u1 = (int)c1, u2 = (int)c2;  // symbols of the staged runs not yet used, taken from the top down
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const uint32_t below = (1u << (2 * k)) - 1u;
             const uint32_t mv = (rr.ops >> (2 * k)) & 3u;
-            // symbols consumed before code k = k - (lefts | ups below it); the staged run starts at i - c1
-            const uint32_t u1 = c1 - 1 - (k - __popc(is_left & below));
-            const uint32_t u2 = c2 - 1 - (k - __popc(is_up & below));
-            const bool in = (uint32_t)k < rr.count;
-            const uint32_t x = (!in || mv == BA_MV_LEFT) ? gs : (uint32_t)b1[u1];
-            const uint32_t y = (!in || mv == BA_MV_UP) ? gs : (uint32_t)b2[u2];
+            u1 -= (mv != BA_MV_LEFT);
+            u2 -= (mv != BA_MV_UP);
+            const uint32_t xs = b1[max(u1, 0)], ys = b2[max(u2, 0)];
+            const uint32_t x = mv == BA_MV_LEFT ? gs : xs;
+            const uint32_t y = mv == BA_MV_UP ? gs : ys;
             // code k is trace column end - 16r - 1 - k: byte 15 - k of the record's 16-byte chunk
             a[(15 - k) >> 2] |= x << (((15 - k) & 3) * 8);
             b[(15 - k) >> 2] |= y << (((15 - k) & 3) * 8);

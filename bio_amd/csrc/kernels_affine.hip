@@ -182,7 +182,10 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, BA_AFF_WPE) ba_dp_affine_ker
         };
         auto publish = [&](int groups) {
             if (!PIPE) return;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the boundary stores are out before the word says so
+            // the boundary stores have been acknowledged before the word says so (the fence alone may
+            // be lowered without a vmcnt wait at workgroup scope)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             prog[wave] = ((uint32_t)round << 16) + (uint32_t)groups;
         };
         const int i0 = n - (strips - s) * R;

@@ -40,13 +40,12 @@ __device__ __forceinline__ int ba_wave_shl1(int last, int src)
     return __builtin_amdgcn_update_dpp(last, src, 0x130, 0xf, 0xf, false);
 }
 
-// Waits until every store this wave has issued has been acknowledged (s_waitcnt vmcnt(0);
-// gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima),
-// and keeps the compiler from moving memory operations across it.
+// Waits until every store this wave has issued has been acknowledged, and keeps the compiler
+// from moving memory operations across it.
 __device__ __forceinline__ void ba_stores_done()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // inline asm: the waitcnt pass cannot drop it (MI355X_MICROARCH.md, compiler hazard)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 }
 
@@ -479,7 +478,13 @@ __global__ void __launch_bounds__(1024) ba_long_expand_kernel(BaLongParams P)
 template <int MODE, int T, int K>
 static hipError_t launch_long(const BaLongParams &P, hipStream_t st)
 {
-    hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K>), dim3(P.strips), dim3(64), 0, st, P);
+    // 84 KB of (unused) dynamic LDS: at most one strip per CU, the placement the sc1 hand-off was measured in
+    // (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads"); strips beyond the CU count queue up behind
+    // the ones they depend on
+    const size_t pad_lds = 84 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
+    hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K>), dim3(P.strips), dim3(64), pad_lds, st, P);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ba_long_walk_kernel<MODE, T, K>), dim3(1), dim3(64), 0, st, P);
