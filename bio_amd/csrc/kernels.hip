@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     using G = BaTraceGeom<R, K>;
     constexpr int F = G::F, WPC = G::WPC, CHW = G::CHW, BG = G::BG, BW = G::BW;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: the bundle record and all it implies live in SGPRs
     const int waves = blockDim.x >> 6;
     const uint32_t b_idx = P.bundle_begin + blockIdx.x * waves + wave;
     if (b_idx >= P.bundle_end) return;
@@ -538,8 +538,10 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
         uint4 q[BG];
 #pragma unroll
         for (int k = 0; k < BG; ++k) {
-            const int cg = cg_hi - (BG - 1) + k;
-            q[k] = cg >= 0 ? block_words(rb, cg) : make_uint4(0, 0, 0, 0);
+            // unconditional (column groups left of the matrix are clamped and never looked at): the loads
+            // of a band issue back to back and share one wait
+            const int cg = max(cg_hi - (BG - 1) + k, 0);
+            q[k] = block_words(rb, cg);
         }
         uint32_t *dst = band + (size_t)which * BW * 64;
 #pragma unroll
@@ -556,6 +558,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     int i_top = i;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) i_top = max(i_top, __shfl_xor(i_top, d));
+    i_top = __builtin_amdgcn_readfirstlane(i_top);  // uniform: the row loop's bookkeeping runs on the scalar unit
     int last_rb = -1;
     for (int iu = i_top; iu >= 1; --iu) {
         const int t = iu - 1 + front;

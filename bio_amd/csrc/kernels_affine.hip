@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(256) ba_trace_affine_kernel(BaTraceParams P)
     extern __shared__ __align__(16) uint32_t lds[];
     constexpr int CPW = 32 / R;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: the bundle record and all it implies live in SGPRs
     const int waves = blockDim.x >> 6;
     const int tbl_words = (P.na * P.nb + 3) & ~3;
     int32_t *tbl = reinterpret_cast<int32_t *>(lds);
