@@ -6,7 +6,7 @@ CSRC := bio_amd/csrc
 LIB := bio_amd/lib/libbioalign.so
 OBJS := build/kernels.o build/kernels_affine.o build/kernels_long.o build/api.o
 
-all: $(LIB) oracle
+all: $(LIB) oracle tests/cpp/bio_test
 
 $(LIB): $(OBJS)
 	@mkdir -p bio_amd/lib
@@ -28,11 +28,15 @@ build/api.o: $(CSRC)/api.cpp $(CSRC)/common.h include/bioalign.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -x hip -c -o $@ $<
 
+# C++ host mirror (include/bio.hpp) and its tests; plain g++, links the C ABI only
+tests/cpp/bio_test: tests/cpp/bio_test.cpp tests/cpp/golden_vectors.inc include/bio.hpp include/bio_matrices.inc include/bioalign.h $(LIB)
+	g++ -O2 -std=c++17 -Wall -o $@ tests/cpp/bio_test.cpp -Lbio_amd/lib -lbioalign -Wl,-rpath,'$$ORIGIN/../../bio_amd/lib'
+
 oracle:
 	$(MAKE) -C oracle libbio_oracle.so
 
 clean:
-	rm -rf build $(LIB)
+	rm -rf build $(LIB) tests/cpp/bio_test
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -1,0 +1,260 @@
+// bio.hpp -- C++ host mirror of soniakeys/bio's alignment API over the C ABI of bioalign.h.
+//
+// The reference is compiled code (Go); this image has no Go toolchain, so the host side a Go
+// maintainer would write with cgo is mirrored here in C++: same names, same
+// argument meaning, same error behaviour (a Go panic is a C++ exception, a nil slice an empty
+// string).  Everything is computed by the HIP library; nothing here aligns on the CPU.
+//
+//   reference                                   here
+//   type Seq []byte              (seq.go:18)    bio::Seq = std::string (bytes)
+//   var GapSymbol byte           (align.go:3)   bio::GapSymbol
+//   type Aligner interface       (align.go:5-8) bio::Aligner
+//   SubstMatrix, NewSubstMatrix  (subst_matrix.go:8-32)
+//   Blosum62, Pam250             (subst_matrix.go:34-61)
+//   LinearGap, ConstantGap       (align.go:18-69)
+//   AlignGlobal, AlignLocal      (align.go:76, 152)
+//   AlignPair                    (align_pair.go:3)
+//   AlignGlobalLS                (align_linear.go:9)
+//   AlignGlobalAffine            (align_affine.go:12)
+//   + AlignPairBatch, AlignAffineBatch, AlignPairLong (additive)
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "bioalign.h"
+
+namespace bio {
+
+using Seq = std::string;
+inline uint8_t GapSymbol = '-';  // align.go:3, read at call time
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error("bioalign error " + std::to_string(c) + ": " + m), code(c) {}
+};
+
+struct Aligner {  // align.go:5-8
+    virtual ~Aligner() = default;
+    virtual int Score(uint8_t x, uint8_t y) const = 0;
+};
+
+struct SubstMatrix : Aligner {  // subst_matrix.go:8-17
+    std::string Alphabet;
+    std::vector<std::vector<int>> Matrix;
+    std::vector<int> Index;  // zero filled up to the largest alphabet byte: smaller foreign bytes alias to symbol 0
+    int Score(uint8_t x, uint8_t y) const override { return Matrix.at(Index.at(x)).at(Index.at(y)); }  // .at: the Go panic
+};
+
+inline SubstMatrix NewSubstMatrix(const std::string &alphabet, std::vector<std::vector<int>> matrix)
+{  // subst_matrix.go:20-32
+    SubstMatrix m;
+    m.Alphabet = alphabet;
+    m.Matrix = std::move(matrix);
+    int mx = 0;
+    for (unsigned char b : alphabet) mx = b > mx ? b : mx;
+    m.Index.assign(alphabet.empty() ? 1 : mx + 1, 0);
+    for (size_t i = 0; i < alphabet.size(); ++i) m.Index[(unsigned char)alphabet[i]] = (int)i;
+    return m;
+}
+
+namespace detail {
+#include "bio_matrices.inc"
+inline SubstMatrix builtin(const char *alphabet, const int (&t)[20][20])
+{
+    std::vector<std::vector<int>> m(20, std::vector<int>(20));
+    for (int i = 0; i < 20; ++i)
+        for (int j = 0; j < 20; ++j) m[i][j] = t[i][j];
+    return NewSubstMatrix(alphabet, std::move(m));
+}
+}  // namespace detail
+
+inline const SubstMatrix &Blosum62()
+{
+    static const SubstMatrix m = detail::builtin(detail::kBlosum62Alphabet, detail::kBlosum62);
+    return m;
+}
+inline const SubstMatrix &Pam250()
+{
+    static const SubstMatrix m = detail::builtin(detail::kPam250Alphabet, detail::kPam250);
+    return m;
+}
+
+// match / mismatch scorer, as the reference's tests define locally (align_fitting_test.go:9-16)
+struct MatchAligner : Aligner {
+    int match, mismatch;
+    MatchAligner(int ma, int mi) : match(ma), mismatch(mi) {}
+    int Score(uint8_t x, uint8_t y) const override { return x == y ? match : mismatch; }
+};
+
+inline int LinearGap(const Seq &s, const Seq &t, const Aligner &a, int gapPenalty)
+{  // align.go:18-31
+    if (s.size() != t.size()) throw std::runtime_error("Sequences have different lengths");
+    int score = 0;
+    for (size_t i = 0; i < s.size(); ++i) {
+        const uint8_t sa = (uint8_t)s[i], ta = (uint8_t)t[i];
+        if (sa == GapSymbol || ta == GapSymbol) score -= gapPenalty;
+        else score += a.Score(sa, ta);
+    }
+    return score;
+}
+
+inline int ConstantGap(const Seq &s, const Seq &t, const Aligner &a, int gapPenalty)
+{  // align.go:41-69
+    if (s.size() != t.size()) throw std::runtime_error("Sequences have different lengths");
+    int score = 0, open = 0;  // 0 none, 1 gap in s, 2 gap in t
+    for (size_t i = 0; i < s.size(); ++i) {
+        const uint8_t sa = (uint8_t)s[i], ta = (uint8_t)t[i];
+        if (sa == GapSymbol) {
+            if (open != 1) score -= gapPenalty, open = 1;
+        } else if (ta == GapSymbol) {
+            if (open != 2) score -= gapPenalty, open = 2;
+        } else {
+            score += a.Score(sa, ta);
+            open = 0;
+        }
+    }
+    return score;
+}
+
+struct Alignment {  // (score, t1, t2); empty strings are the reference's nil slices
+    long long score = 0;
+    Seq t1, t2;
+    bool operator==(const Alignment &o) const { return score == o.score && t1 == o.t1 && t2 == o.t2; }
+};
+
+namespace detail {
+inline bioalign_ctx *engine()
+{
+    static bioalign_ctx *ctx = bioalign_create(nullptr, 0);
+    if (!ctx) throw Error(BIOALIGN_ENODEVICE, bioalign_last_error(nullptr));  // no CPU fallback
+    return ctx;
+}
+inline int mode_of(const std::string &mode)
+{
+    if (mode == "global") return BIOALIGN_GLOBAL;
+    if (mode == "local") return BIOALIGN_LOCAL;
+    if (mode == "fitting") return BIOALIGN_FITTING;
+    if (mode == "overlap") return BIOALIGN_OVERLAP;
+    return -1;
+}
+// Score is called once per (s1 byte, s2 byte) pair that occurs; an exception propagates
+inline std::vector<Alignment> run(const std::string &mode, const std::vector<Seq> &s1s, const std::vector<Seq> &s2s,
+                                  const Aligner &a, int gap_open, int gap_extend, bool longmode)
+{
+    if (s1s.size() != s2s.size()) throw std::invalid_argument("s1s and s2s must have the same length");
+    const size_t n = s1s.size();
+    std::vector<Alignment> res(n);
+    const int m = mode_of(mode);
+    if (m < 0) {  // align_pair.go:14-15
+        for (auto &r : res) r.score = -1;
+        return res;
+    }
+    if (n == 0) return res;
+    std::vector<uint64_t> o1(n + 1, 0), o2(n + 1, 0);
+    std::string c1, c2;
+    std::array<bool, 256> seen1{}, seen2{};
+    for (size_t p = 0; p < n; ++p) {
+        c1 += s1s[p];
+        c2 += s2s[p];
+        o1[p + 1] = c1.size();
+        o2[p + 1] = c2.size();
+        for (unsigned char b : s1s[p]) seen1[b] = true;
+        for (unsigned char b : s2s[p]) seen2[b] = true;
+    }
+    std::array<uint8_t, 256> code1{}, code2{};
+    std::vector<uint8_t> b1, b2;
+    for (int b = 0; b < 256; ++b) {
+        if (seen1[b]) code1[b] = (uint8_t)b1.size(), b1.push_back((uint8_t)b);
+        if (seen2[b]) code2[b] = (uint8_t)b2.size(), b2.push_back((uint8_t)b);
+    }
+    const int na = b1.empty() ? 1 : (int)b1.size(), nb = b2.empty() ? 1 : (int)b2.size();
+    std::vector<int32_t> table((size_t)na * nb, 0);
+    for (size_t i = 0; i < b1.size(); ++i)
+        for (size_t j = 0; j < b2.size(); ++j) table[i * nb + j] = a.Score(b1[i], b2[j]);
+    const size_t cap = c1.size() + c2.size();
+    std::vector<int64_t> sc(n);
+    std::vector<uint8_t> t1(cap + 1), t2(cap + 1);
+    std::vector<uint64_t> toff(n), tlen(n);
+    c1.push_back(0);
+    c2.push_back(0);
+    bioalign_batch_t in{};
+    in.s1 = (const uint8_t *)c1.data();
+    in.s1_off = o1.data();
+    in.s2 = (const uint8_t *)c2.data();
+    in.s2_off = o2.data();
+    in.n_pairs = n;
+    in.mode = m;
+    in.score_table = table.data();
+    in.na = na;
+    in.nb = nb;
+    in.code1 = code1.data();
+    in.code2 = code2.data();
+    in.gap_open = gap_open;
+    in.gap_extend = gap_extend;
+    in.gap_symbol = GapSymbol;
+    bioalign_result_t out{sc.data(), t1.data(), t2.data(), toff.data(), tlen.data()};
+    bioalign_ctx *ctx = engine();
+    const int rc = longmode ? bioalign_long(ctx, &in, &out, nullptr) : bioalign_batch(ctx, &in, &out);
+    if (rc != 0) throw Error(rc, bioalign_last_error(ctx));
+    for (size_t p = 0; p < n; ++p) {
+        res[p].score = sc[p];
+        res[p].t1.assign((const char *)t1.data() + toff[p], tlen[p]);
+        res[p].t2.assign((const char *)t2.data() + toff[p], tlen[p]);
+    }
+    return res;
+}
+}  // namespace detail
+
+// additive batch entry points
+inline std::vector<Alignment> AlignPairBatch(const std::string &mode, const std::vector<Seq> &s1s, const std::vector<Seq> &s2s,
+                                             const Aligner &a, int indelPenalty)
+{
+    return detail::run(mode, s1s, s2s, a, indelPenalty, indelPenalty, false);
+}
+inline std::vector<Alignment> AlignAffineBatch(const std::string &mode, const std::vector<Seq> &s1s, const std::vector<Seq> &s2s,
+                                               const Aligner &a, int gapOpenPenalty, int gapExtendPenalty)
+{
+    return detail::run(mode, s1s, s2s, a, gapOpenPenalty, gapExtendPenalty, false);
+}
+
+inline Alignment AlignPair(const std::string &mode, const Seq &s1, const Seq &s2, const Aligner &a, int indelPenalty)
+{  // align_pair.go:3-21
+    return detail::run(mode, {s1}, {s2}, a, indelPenalty, indelPenalty, false)[0];
+}
+inline Alignment AlignPairLong(const std::string &mode, const Seq &s1, const Seq &s2, const Aligner &a, int indelPenalty)
+{  // AlignPair for one long pair: the intra-sequence wavefront kernels (bioalign_long)
+    return detail::run(mode, {s1}, {s2}, a, indelPenalty, indelPenalty, true)[0];
+}
+inline Alignment AlignGlobal(const Seq &s1, const Seq &s2, const Aligner &a, int indelPenalty)
+{  // align.go:76-145; with an empty s2 the reference indexes s2[-1] (align.go:128-130) and panics
+    if (s2.empty() && !s1.empty()) throw std::out_of_range("index out of range [-1]");
+    return AlignPair("global", s1, s2, a, indelPenalty);
+}
+inline Alignment AlignLocal(const Seq &s1, const Seq &s2, const Aligner &a, int indelPenalty)
+{  // align.go:152-249
+    return AlignPair("local", s1, s2, a, indelPenalty);
+}
+inline Alignment AlignGlobalLS(const Seq &s1, const Seq &s2, const Aligner &a, int indelPenalty)
+{  // align_linear.go:9-45: AlignGlobal's result (align_test.go:55-66); long inputs take the long-mode kernels
+    if ((unsigned long long)s1.size() * s2.size() >= (1ull << 24)) {
+        std::array<bool, 256> seen{};
+        int distinct = 0;
+        for (unsigned char b : s2) distinct += !seen[b], seen[b] = true;
+        if (distinct <= 4) return AlignPairLong("global", s1, s2, a, indelPenalty);
+    }
+    return AlignPair("global", s1, s2, a, indelPenalty);
+}
+inline std::tuple<double, Seq, Seq> AlignGlobalAffine(const Seq &s1, const Seq &s2, const Aligner &a, double gapOpenPenalty,
+                                                      double gapExtendPenalty)
+{  // align_affine.go:12-167: float64 score, integer arithmetic underneath (whole-number penalties)
+    if (gapOpenPenalty != (long long)gapOpenPenalty || gapExtendPenalty != (long long)gapExtendPenalty)
+        throw std::invalid_argument("AlignGlobalAffine on the GPU path needs integer-valued penalties");
+    Alignment r = detail::run("global", {s1}, {s2}, a, (int)gapOpenPenalty, (int)gapExtendPenalty, false)[0];
+    return {(double)r.score, r.t1, r.t2};
+}
+
+}  // namespace bio

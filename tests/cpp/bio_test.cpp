@@ -1,0 +1,128 @@
+// C++ host-mirror tests, written like the reference's own Example tests (align_test.go,
+// align_fitting_test.go, align_overlap_test.go): every golden vector through bio.hpp, plus the
+// reference's error behaviour.   bio_test --cpu : what needs no GPU;   bio_test --gpu : everything.
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "../../include/bio.hpp"
+#include "golden_vectors.inc"
+
+static int failures = 0;
+#define CHECK(cond, ...)                                   \
+    do {                                                   \
+        if (!(cond)) {                                     \
+            ++failures;                                    \
+            std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+            std::printf(__VA_ARGS__);                      \
+            std::printf("\n");                             \
+        }                                                  \
+    } while (0)
+
+static std::unique_ptr<bio::Aligner> aligner_of(const Golden &g)
+{
+    if (!std::strcmp(g.aligner, "Blosum62")) return std::make_unique<bio::SubstMatrix>(bio::Blosum62());
+    if (!std::strcmp(g.aligner, "Pam250")) return std::make_unique<bio::SubstMatrix>(bio::Pam250());
+    return std::make_unique<bio::MatchAligner>(g.match, g.mismatch);
+}
+
+static void cpu_tests()
+{
+    for (const Golden &g : kGolden) {
+        auto a = aligner_of(g);
+        if (!std::strcmp(g.fn, "LinearGap")) CHECK(bio::LinearGap(g.s1, g.s2, *a, g.gap) == g.score, "%s", g.id);
+        if (!std::strcmp(g.fn, "ConstantGap")) CHECK(bio::ConstantGap(g.s1, g.s2, *a, g.gap) == g.score, "%s", g.id);
+    }
+    const bio::SubstMatrix &b = bio::Blosum62();
+    CHECK(b.Score('W', 'W') == 11 && b.Score('A', 'R') == -1, "Blosum62 entries");
+    CHECK(b.Score('B', 'W') == b.Score('A', 'W'), "foreign byte below max aliases to symbol 0 (subst_matrix.go:27-30)");
+    bool threw = false;
+    try { b.Score('a', 'A'); } catch (const std::out_of_range &) { threw = true; }
+    CHECK(threw, "byte above max panics");
+    CHECK(bio::Pam250().Score('W', 'W') == 17, "Pam250 entry");
+    threw = false;
+    try { bio::LinearGap("AC", "A", b, 1); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw, "LinearGap panics on unequal lengths (align.go:19-21)");
+    const uint8_t old = bio::GapSymbol;
+    bio::GapSymbol = '.';
+    CHECK(bio::LinearGap("A.", "AC", bio::MatchAligner(1, -1), 3) == 1 - 3, "GapSymbol is read at call time");
+    bio::GapSymbol = old;
+    // unknown mode: (-1, nil, nil), never reaches the device (align_pair.go:14-15)
+    bio::Alignment r = bio::AlignPair("semi-global", "AC", "AC", b, 1);
+    CHECK(r.score == -1 && r.t1.empty() && r.t2.empty(), "unknown mode");
+    threw = false;
+    try { bio::AlignGlobal("AC", "", b, 1); } catch (const std::out_of_range &) { threw = true; }
+    CHECK(threw, "AlignGlobal with an empty s2 panics (align.go:128-130)");
+}
+
+static void gpu_tests()
+{
+    for (const Golden &g : kGolden) {
+        auto a = aligner_of(g);
+        bio::Alignment want{g.score, g.t1, g.t2}, got;
+        if (!std::strcmp(g.fn, "AlignGlobal")) got = bio::AlignGlobal(g.s1, g.s2, *a, g.gap);
+        else if (!std::strcmp(g.fn, "AlignLocal")) got = bio::AlignLocal(g.s1, g.s2, *a, g.gap);
+        else if (!std::strcmp(g.fn, "AlignGlobalLS")) got = bio::AlignGlobalLS(g.s1, g.s2, *a, g.gap);
+        else if (!std::strcmp(g.fn, "AlignPair")) got = bio::AlignPair(g.mode, g.s1, g.s2, *a, g.gap);
+        else continue;
+        CHECK(got == want, "%s: got (%lld, %s, %s)", g.id, got.score, got.t1.c_str(), got.t2.c_str());
+    }
+    const bio::SubstMatrix &b = bio::Blosum62();
+    CHECK((bio::AlignGlobal("", "", b, 5) == bio::Alignment{0, "", ""}), "empty inputs give nil traces");
+    CHECK((bio::AlignPair("global", "AC", "", b, 5) == bio::Alignment{-10, "AC", "--"}), "AlignPair global with empty s2");
+    CHECK((bio::AlignLocal("W", "A", b, 5) == bio::Alignment{0, "", ""}), "nothing positive: 0, nil, nil");
+    bool threw = false;
+    try { bio::AlignGlobal("a", "A", b, 5); } catch (const std::out_of_range &) { threw = true; }
+    CHECK(threw, "lower case is beyond Index: panic while the score table is materialised");
+    // batch = the single-pair results
+    std::vector<bio::Seq> s1s = {"PLEASANTLY", "MEANLY", "", "PAWHEAE"}, s2s = {"MEANLY", "PENALTY", "AC", "HEAGAWGHEE"};
+    auto batch = bio::AlignPairBatch("local", s1s, s2s, b, 5);
+    for (size_t p = 0; p < s1s.size(); ++p) CHECK(batch[p] == bio::AlignLocal(s1s[p], s2s[p], b, 5), "batch pair %zu", p);
+    // affine: the trace spells the inputs and rescoring it gives the score (open 5, extend 1)
+    auto [sc, t1, t2] = bio::AlignGlobalAffine("ACDDE", "ACE", b, 5, 1);
+    std::string u1, u2;
+    for (char ch : t1) if (ch != '-') u1 += ch;
+    for (char ch : t2) if (ch != '-') u2 += ch;
+    CHECK(u1 == "ACDDE" && u2 == "ACE" && t1.size() == t2.size(), "affine trace spells its inputs");
+    double resc = 0;
+    int open = 0;
+    for (size_t k = 0; k < t1.size(); ++k) {
+        if (t1[k] == '-') resc -= (open == 1 ? 1 : 5), open = 1;
+        else if (t2[k] == '-') resc -= (open == 2 ? 1 : 5), open = 2;
+        else resc += b.Score((uint8_t)t1[k], (uint8_t)t2[k]), open = 0;
+    }
+    CHECK(resc == sc, "affine rescoring: %g vs %g", resc, sc);
+    threw = false;
+    try { bio::AlignAffineBatch("global", {"ACGT"}, {"ACG"}, bio::MatchAligner(1, -1), 1, 3); } catch (const bio::Error &e) { threw = e.code == BIOALIGN_EUNSUPPORTED; }
+    CHECK(threw, "open < extend fails loudly");
+    // long mode = the batch result
+    bio::Seq x, y;
+    uint64_t st = 12345;
+    for (int k = 0; k < 900; ++k) { st = st * 6364136223846793005ull + 1442695040888963407ull; x += "ACGT"[(st >> 33) & 3]; }
+    y = x;
+    for (int k = 7; k < 900; k += 37) y[k] = y[k] == 'A' ? 'C' : 'A';
+    y.erase(300, 5);
+    bio::MatchAligner dna(1, -1);
+    CHECK(bio::AlignPairLong("global", x, y, dna, 1) == bio::AlignPair("global", x, y, dna, 1), "long mode = batch mode");
+}
+
+int main(int argc, char **argv)
+{
+    const bool gpu = argc > 1 && !std::strcmp(argv[1], "--gpu");
+    cpu_tests();
+    if (gpu) {
+        try {
+            gpu_tests();
+        } catch (const std::exception &e) {
+            std::printf("FAIL: exception: %s\n", e.what());
+            ++failures;
+        }
+    } else {
+        // without a GPU the engine must refuse loudly
+        bool refused = false;
+        try { bio::AlignPair("global", "ACGT", "ACG", bio::MatchAligner(1, -1), 1); } catch (const bio::Error &e) { refused = e.code == BIOALIGN_ENODEVICE; }
+        if (argc > 2 && !std::strcmp(argv[2], "--expect-no-device")) CHECK(refused, "no GPU: BIOALIGN_ENODEVICE");
+    }
+    std::printf(failures ? "%d failure(s)\n" : "ok\n", failures);
+    return failures ? 1 : 0;
+}
