@@ -1,0 +1,97 @@
+"""GPU tests of the runtime around the kernels: the multi-device split of bioalign_batch (exercised with the
+same GPU listed twice: two host threads, two streams, two plans), workspace chunking, the optional code paths
+behind environment switches, and the limits that must be refused loudly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import bio_amd
+from bio_amd import _native, synth
+from oracle import oracle as O
+
+
+def _batch(mode, s1, o1, s2, o2, eng=None, go=1, ge=1):
+    table, c1, c2 = synth.dna_table(1, -1)
+    eng = eng or _native.Engine([0])
+    return eng.batch(_native.PackedBatch(s1, o1, s2, o2, mode, table, c1, c2, go, ge))
+
+
+def _traces(res):
+    scores, t1, t2, toff, tlen = res
+    return [(int(scores[p]), t1[int(toff[p]):int(toff[p] + tlen[p])].tobytes(), t2[int(toff[p]):int(toff[p] + tlen[p])].tobytes())
+            for p in range(len(scores))]
+
+
+def _ragged(n_pairs, seed):
+    rng = np.random.default_rng(seed)
+    l1 = rng.integers(0, 70, n_pairs)
+    l2 = rng.integers(0, 70, n_pairs)
+    o1 = np.concatenate([[0], np.cumsum(l1)]).astype(np.uint64)
+    o2 = np.concatenate([[0], np.cumsum(l2)]).astype(np.uint64)
+    s1 = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(o1[-1]))]
+    s2 = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(o2[-1]))]
+    return s1, o1, s2, o2
+
+
+@pytest.mark.parametrize("mode", ["global", "local"])
+def test_two_device_split_equals_one_device(mode):
+    s1, o1, s2, o2 = _ragged(3000, 5)
+    one = _traces(_batch(mode, s1, o1, s2, o2))
+    two = _traces(_batch(mode, s1, o1, s2, o2, eng=_native.Engine([0, 0])))
+    assert two == one
+    oa = O.MatchAligner(1, -1)
+    for p in range(0, 3000, 61):
+        x, y = s1[int(o1[p]):int(o1[p + 1])].tobytes(), s2[int(o2[p]):int(o2[p + 1])].tobytes()
+        sc, a, b = O.AlignPair(mode, x, y, oa, 1)
+        assert one[p] == (sc, a or b"", b or b"")
+
+
+def test_workspace_chunking(monkeypatch):
+    s1, o1, s2, o2 = synth.dna_pairs(2000, 100, 100, config=1)
+    whole_linear = _traces(_batch("fitting", s1, o1, s2, o2))
+    whole_affine = _traces(_batch("global", s1, o1, s2, o2, go=4, ge=1))
+    monkeypatch.setenv("BIOALIGN_WORKSPACE_BYTES", str(3 << 20))  # a few bundles per chunk
+    assert _traces(_batch("fitting", s1, o1, s2, o2)) == whole_linear
+    assert _traces(_batch("global", s1, o1, s2, o2, go=4, ge=1)) == whole_affine
+
+
+@pytest.mark.parametrize("mode", ["global", "local", "overlap"])
+def test_fused_byte_writing_walk_matches(mode, monkeypatch):
+    # BIOALIGN_TRACE_BYTES=1: the older walk that writes the bytes itself (kernels.hip, OPS == false)
+    s1, o1, s2, o2 = _ragged(1500, 11)
+    ref = _traces(_batch(mode, s1, o1, s2, o2))
+    monkeypatch.setenv("BIOALIGN_TRACE_BYTES", "1")
+    assert _traces(_batch(mode, s1, o1, s2, o2)) == ref
+
+
+def test_sliced_two_stream_run_matches(monkeypatch):
+    # BIOALIGN_SLICES: traceback of slice k on a second stream under the DP of slice k+1
+    N = 64 * 4200
+    s1, o1, s2, o2 = synth.dna_pairs(N, 12, 12, config=1)
+    ref = _batch("global", s1, o1, s2, o2)
+    monkeypatch.setenv("BIOALIGN_SLICES", "4")
+    got = _batch("global", s1, o1, s2, o2)
+    assert np.array_equal(got[0], ref[0]) and _traces(got)[::997] == _traces(ref)[::997]
+
+
+def test_affine_unpipelined_matches_pipelined(monkeypatch):
+    s1, o1, s2, o2 = synth.fitting_reads(300, 100, 300, config=4)
+    piped = _traces(_batch("fitting", s1, o1, s2, o2, go=5, ge=1))
+    monkeypatch.setenv("BIOALIGN_PIPE_BELOW", "0")
+    assert _traces(_batch("fitting", s1, o1, s2, o2, go=5, ge=1)) == piped
+
+
+def test_limits_are_refused_not_computed_elsewhere():
+    a = bio_amd.MatchAligner(1, -1)
+
+    class Big:
+        def Score(self, x, y):
+            return 300 if x == y else -300
+
+    for fn in (lambda: bio_amd.AlignPairBatch("global", [b"ACGT"], [b"ACG"], Big(), 1),
+               lambda: bio_amd.AlignPairBatch("global", [b"ACGT"], [b"ACG"], a, -1),
+               lambda: bio_amd.AlignPairBatch("global", [b"ACGT"], [b"ACG"], a, 200)):
+        with pytest.raises(_native.BioAlignError) as e:
+            fn()
+        assert e.value.code == _native.EUNSUPPORTED
