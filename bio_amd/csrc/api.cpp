@@ -241,7 +241,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
 
     // int8 profile with the bias folded in (kernels.hip: biased score space)
     // (affine: every level is biased by ext*(i+j) and the strip keeps H' - (open - ext), kernels_affine.hip)
-    const int bias = pl->affine ? pl->gap_open + pl->gap_ext : (pl->mode == BIOALIGN_LOCAL) ? 0 : 2 * pl->gap;
+    const int bias = pl->affine ? pl->gap_open + pl->gap_ext : (pl->mode == BIOALIGN_LOCAL) ? pl->gap : 2 * pl->gap;
     int wmax = 0;
     for (int i = 0; i < pl->na * pl->nb; ++i) {
         const int64_t v = (int64_t)in->score_table[i] + bias;

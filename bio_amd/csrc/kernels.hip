@@ -142,7 +142,9 @@ __device__ __forceinline__ void ba_linear_column(int (&h)[R], int (&rmax)[R / 2]
         const int d = diag + ba_sbyte(pw[r >> 2], r & 3);
         int hn;
         if (MODE == BA_LOCAL) {
-            hn = ba_max3(max(up, left) - g, d, 0);
+            // max(0, max(up, left) - g, diag + w) with w + g in the profile: one max3 and one
+            // saturating unsigned subtract (v_sub_u32 clamp); max3 >= up >= 0, so unsigned is exact
+            hn = (int)__builtin_elementwise_sub_sat((uint32_t)ba_max3(up, left, d), (uint32_t)g);
             // running maximum per PAIR of rows: one v_max3_i32 per two cells
             if (r & 1) rmax[r / 2] = ba_max3(rmax[r / 2], up, hn);
         } else {
