@@ -129,15 +129,21 @@ __global__ void __launch_bounds__(256) ba_pack_kernel(BaPackParams P)
 // ----------------------------------------------------------------------------
 // linear-gap DP: one column of one strip (R rows in VGPRs)
 // ----------------------------------------------------------------------------
-template <int MODE, int R, int K>
+// R0: first row of the strip that is computed.  The first strip of a pair starts with `front`
+// rows that lie above the matrix; they only reproduce row 0, which `top` / `topdiag` already
+// are, so the first R0 <= front of them are skipped (their residue fields are never read, and
+// the fields of the rows that are computed land where they always do: v_alignbit fills a
+// word from the top).
+template <int MODE, int R, int K, int R0>
 __device__ __forceinline__ void ba_linear_column(int (&h)[R], int (&rmax)[R / 2], uint32_t (&acc)[R * K / 32],
                                                  const uint32_t (&pw)[R / 4], int top, int &topdiag, int g)
 {
     constexpr int F = 32 / K;  // residues per word
+    static_assert(R0 % 2 == 0 && R0 < R, "R0 must be even and leave rows to compute");
     int up = top, diag = topdiag;
     topdiag = top;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = R0; r < R; ++r) {
         const int left = h[r];
         const int d = diag + ba_sbyte(pw[r >> 2], r & 3);
         int hn;
@@ -264,8 +270,9 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
         };
         // one group of 4 columns (one packed s2 word): FULL groups run without any
         // per-column test so that the strip stays in the same registers all along
-        auto column_group = [&](int cg, const GroupIn &in, auto full) {
+        auto column_group = [&](int cg, const GroupIn &in, auto full, auto first_row) {
             constexpr bool FULL = decltype(full)::value;
+            constexpr int R0 = decltype(first_row)::value;
             const int jbase = cg * 4 + 1;
             const uint32_t bw = (s == 0) ? bd_row0 : in.bw;
             const int sh0 = ((cg * 4) % F) * K;  // uniform
@@ -289,7 +296,7 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
                     // score above this column = score above the previous one + the stored step
                     const int top = topdiag + (int)((bw >> (sh0 + c * K)) & MASK) - off;
                     const int old_last = h[R - 1];
-                    ba_linear_column<MODE, R, K>(h, rmax, acc[c], pw, top, topdiag, g);
+                    ba_linear_column<MODE, R, K, R0>(h, rmax, acc[c], pw, top, topdiag, g);
                     accb = __builtin_amdgcn_alignbit((uint32_t)(h[R - 1] - old_last + off), accb, K);
                     if ((MODE == BA_FITTING || MODE == BA_OVERLAP) && last_strip) {
                         const int v = h[R - 1] - g * (jbase + c);
@@ -307,14 +314,25 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
             if (FULL && !last_strip && ((cg + 1) * 4) % F == 0) bd_wr[(size_t)((cg * 4) / F) * 64] = accb;
         };
         const int full_groups = m / 4;
-        if (cgs > 0) {
+        auto sweep = [&](auto first_row) {
             GroupIn nxt = fetch_group(0);
             for (int cg = 0; cg < full_groups; ++cg) {
                 const GroupIn cur = nxt;
                 nxt = fetch_group(min(cg + 1, cgs - 1));
-                column_group(cg, cur, std::true_type{});
+                column_group(cg, cur, std::true_type{}, first_row);
             }
-            if (full_groups < cgs) column_group(full_groups, nxt, std::false_type{});
+            if (full_groups < cgs) column_group(full_groups, nxt, std::false_type{}, first_row);
+        };
+        if (cgs > 0) {
+            // the rows of the first strip that lie above the matrix are skipped in steps of 8
+            // (global and local only: with the end-cell scan of fitting / overlap in the loop the extra
+            // instances cost the kernel its occupancy)
+            constexpr bool TRIM = (MODE == BA_GLOBAL || MODE == BA_LOCAL);
+            const int skip = (TRIM && s == 0) ? (front & ~7) : 0;
+            if (!TRIM || skip == 0) sweep(std::integral_constant<int, 0>{});
+            else if (skip == 8) sweep(std::integral_constant<int, (TRIM ? 8 : 0)>{});
+            else if (R > 16 && skip == 16) sweep(std::integral_constant<int, (TRIM && R > 16 ? 16 : 0)>{});
+            else sweep(std::integral_constant<int, (TRIM && R > 16 ? 24 : 0)>{});
             // the last, partial word of boundary deltas: its m % F fields sit at the top
             if (!last_strip && (m % F) != 0) bd_wr[(size_t)(m / F) * 64] = accb >> ((F - m % F) * K);
         }
