@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     const uint32_t *s2w = P.s2w + B.s2w_off + lane;
     int k1_tag = -1, k2_tag = -1;
     uint32_t x_word = 0, y_word = 0;
-    auto sym1 = [&](int i1) {  // s1[i1-1]; i1 is wave-uniform
+    auto sym1 = [&](int i1) {  // s1[i1-1]
         const int t = i1 - 1 + front;
         if ((t >> 2) != k1_tag) {
             k1_tag = t >> 2;
@@ -550,7 +550,6 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     bool done = !live || (i == 0 && j == 0);
     // band bookkeeping, per lane: which row block each of the two LDS bands holds and its first column
     int tag0 = -1, tag1 = -1, col00 = 0, col01 = 0;
-    int sel = 0;  // uniform: which LDS band belongs to the current row block
 
     // stage the band of row block rb that ends at the column group of column index `col` (0-based)
     auto load_band = [&](int which, int rb, int col) {
@@ -574,26 +573,26 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
         return (cg_hi - (BG - 1)) * 4;  // first column of the band
     };
 
-    // rows n .. 1, all lanes in step
+    // rows n .. 1.  The wavefront moves ROW BLOCK by row block (F rows: one residue word), top block
+    // index in an SGPR; inside a block every lane takes one move per round, whatever row it is in, until
+    // all lanes have left the block upwards (or are finished).  Rounds per block = the longest stretch of
+    // path any lane has inside it.
+    constexpr int LOGF = (F == 16) ? 4 : (F == 8) ? 3 : 2;
+    static_assert((1 << LOGF) == F, "F is 4, 8 or 16");
     int i_top = i;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) i_top = max(i_top, __shfl_xor(i_top, d));
-    i_top = __builtin_amdgcn_readfirstlane(i_top);  // uniform: the row loop's bookkeeping runs on the scalar unit
-    int last_rb = -1;
-    for (int iu = i_top; iu >= 1; --iu) {
-        const int t = iu - 1 + front;
-        const int rb = t / F, f = t % F;
-        if (rb != last_rb) {  // uniform: the band staged as "above" becomes the current one
-            sel ^= 1;
-            last_rb = rb;
-        }
-        const bool need_above = (f == 0) && (iu > 1);  // uniform: row iu-1 lies in row block rb-1
-        const uint32_t x_row = OPS ? 0u : sym1(iu);     // s1[iu-1] of every lane
-        // lanes take their left moves, then leave the row by an up or a diagonal move
+    i_top = __builtin_amdgcn_readfirstlane(i_top);  // uniform: the block loop's bookkeeping runs on the scalar unit
+    const int rb_first = front >> LOGF;             // the block that holds row 1
+    for (int rb = (i_top >= 1) ? ((i_top - 1 + front) >> LOGF) : -1; rb >= rb_first; --rb) {
+        const int sel = rb & 1;  // uniform: which LDS band belongs to this row block (the other one: the block above)
         while (true) {
-            const bool act = !done && i == iu;
+            const int t = i - 1 + front;  // my row, counted over the front-padded rows
+            const bool act = !done && i >= 1 && (t >> LOGF) == rb;
             if (!__any(act)) break;
             if (act) {
+                const int f = t & (F - 1);
+                const uint32_t x_row = OPS ? 0u : sym1(i);  // s1[i-1]
                 if (j == 0) {
                     if (left_free) {
                         done = true;
@@ -622,7 +621,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
                     const uint32_t A = bc[(j - 1 - colc) * 64];
                     const uint32_t Bw = bc[(cl - colc) * 64];
                     uint32_t r_up, r_diag;
-                    if (need_above) {
+                    if (f == 0 && i > 1) {  // row i-1 lies in row block rb-1
                         int taga = sel ? tag0 : tag1, cola = sel ? col00 : col01;
                         if (taga != rb - 1 || cl < cola) {
                             cola = load_band(sel ^ 1, rb - 1, j - 1);
@@ -643,9 +642,9 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
                         // cur = max(0, up - g, left - g, diag + w) > 0 here, skip-prefix first, then up > left >
                         // diagonal (align.go:186-202): the cell came through the diagonal iff it is above both
                         // up - g and left - g.  Exact neighbours follow from the residues; no score table needed.
-                        const int up = (iu == 1) ? 0 : neighbour(cur, r_up);
+                        const int up = (i == 1) ? 0 : neighbour(cur, r_up);
                         const int left = (j == 1) ? 0 : neighbour(cur, r_left);
-                        const int diag = (iu == 1 || j == 1) ? 0 : neighbour(up, r_diag);
+                        const int diag = (i == 1 || j == 1) ? 0 : neighbour(up, r_diag);
                         const bool from_up = cur == up - g, from_left = cur == left - g;
                         mv = (!from_up && !from_left) ? 2 : (from_left && !from_up) ? 1 : 0;
                         cur = mv == 2 ? diag : mv == 1 ? left : up;
@@ -655,10 +654,10 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
                         // (align.go:105-116) -- and "cur > x" is "residues differ".  No score, no table, no
                         // symbol on the decision path; `cur` only carries the current cell's residue.
                         const uint32_t rc = (uint32_t)cur & MASK;
-                        const uint32_t ru = (iu == 1) ? (uint32_t)(b_top * j) & MASK : r_up;
-                        const uint32_t rl = (j == 1) ? (uint32_t)(b_left * iu) & MASK : r_left;
-                        const uint32_t rd = (iu == 1) ? (uint32_t)(b_top * (j - 1)) & MASK
-                                                      : (j == 1) ? (uint32_t)(b_left * (iu - 1)) & MASK : r_diag;
+                        const uint32_t ru = (i == 1) ? (uint32_t)(b_top * j) & MASK : r_up;
+                        const uint32_t rl = (j == 1) ? (uint32_t)(b_left * i) & MASK : r_left;
+                        const uint32_t rd = (i == 1) ? (uint32_t)(b_top * (j - 1)) & MASK
+                                                     : (j == 1) ? (uint32_t)(b_left * (i - 1)) & MASK : r_diag;
                         const bool above_up = rc != ru, above_left = rc != rl;
                         mv = (above_up && above_left) ? 2 : (above_up && !above_left) ? 1 : 0;
                         cur = (int)(mv == 2 ? rd : mv == 1 ? rl : ru);
