@@ -164,19 +164,19 @@ __device__ __forceinline__ void ba_linear_column(int (&h)[R], int (&rmax)[R / 2]
 }
 
 // Layout of the residue words of one bundle (dwords):
-//   [strip][column group cg = (j-1)/4][lane][row block w][column c = (j-1)%4]
+//   [strip][row block w][column group cg = (j-1)/4][lane][column c = (j-1)%4]
 // A word holds F = 32/K consecutive rows of one column (a "row block"); a strip
-// has WPC = R/F row blocks.  A lane's WPC x 4 words of one column group are one
-// contiguous 16*WPC-byte chunk, a wavefront stores a column group as 64 such
-// chunks back to back, and the 4 columns of one row block are one aligned uint4
-// -- the unit the traceback fetches.
+// has WPC = R/F row blocks.  The 4 columns of one row block are one aligned uint4
+// per lane -- the unit the traceback fetches -- and the 64 lanes' uint4s of one
+// (row block, column group) are one contiguous KB: a store of the DP kernel and a
+// load of the walk each touch whole cache lines and nothing else (with the row
+// blocks of a strip interleaved per lane the walk fetched twice what it used).
 template <int MODE, int R, int K>
 __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
 {
     extern __shared__ __align__(16) uint32_t lds[];
     constexpr int HALVES = R / 16;
     constexpr int WPC = R * K / 32;
-    constexpr int CHW = 4 * WPC;  // dwords per lane per column group
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves = blockDim.x >> 6;
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
     constexpr uint32_t REP = 0xffffffffu / MASK;  // every K-bit field = 1
     const int nbw = (m + F - 1) / F;
     uint32_t *bd = reinterpret_cast<uint32_t *>(P.hb) + B.hb_off + lane;
-    uint32_t *dir = P.dir + B.dir_off + (size_t)lane * CHW;
+    uint32_t *dir = P.dir + B.dir_off + (size_t)lane * 4;
     const uint32_t *s1w = P.s1w + B.s1w_off + lane;
     const uint32_t *s2w = P.s2w + B.s2w_off + lane;
     const int off = (MODE == BA_LOCAL) ? g : 0;  // a horizontal step is never below -off
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
             rmax[r / 2] = 0;
         }
         int topdiag = (MODE == BA_OVERLAP) ? g * max(i0, 0) : 0;  // Hs(i0, 0)
-        uint32_t *dirs = dir + (size_t)s * cgs * (64 * CHW);
+        uint32_t *dirs = dir + (size_t)s * WPC * cgs * 256;  // + (w * cgs + cg) * 256
         uint32_t acc[4][WPC];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -308,9 +308,10 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
                     }
                 }
             }
-            uint4 *dst = reinterpret_cast<uint4 *>(dirs + (size_t)cg * (64 * CHW));
 #pragma unroll
-            for (int w = 0; w < WPC; ++w) dst[w] = make_uint4(acc[0][w], acc[1][w], acc[2][w], acc[3][w]);
+            for (int w = 0; w < WPC; ++w)
+                *reinterpret_cast<uint4 *>(dirs + ((size_t)w * cgs + cg) * 256) =
+                    make_uint4(acc[0][w], acc[1][w], acc[2][w], acc[3][w]);
             if (FULL && !last_strip && ((cg + 1) * 4) % F == 0) bd_wr[(size_t)((cg * 4) / F) * 64] = accb;
         };
         const int full_groups = m / 4;
@@ -391,7 +392,6 @@ template <int R, int K>
 struct BaTraceGeom {
     static constexpr int F = 32 / K;           // rows per residue word
     static constexpr int WPC = R / F;          // row blocks per strip
-    static constexpr int CHW = 4 * WPC;        // dwords per lane per column group
     static constexpr int BG = F / 4 + 2;       // column groups per staged band
     static constexpr int BW = BG * 4;          // band width in columns
     static constexpr int WORDS = 2 * BW;       // LDS words per lane (two bands)
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
 {
     extern __shared__ __align__(16) uint32_t lds[];
     using G = BaTraceGeom<R, K>;
-    constexpr int F = G::F, WPC = G::WPC, CHW = G::CHW, BG = G::BG, BW = G::BW;
+    constexpr int F = G::F, BG = G::BG, BW = G::BW;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: the bundle record and all it implies live in SGPRs
     const int waves = blockDim.x >> 6;
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     const uint32_t p = live ? P.perm[B.first + lane] : 0u;
     const int n = (int)B.n, m = (int)B.m;
     const int g = P.gap;
-    const uint32_t *dir = P.dir + B.dir_off + (size_t)lane * CHW;
+    const uint32_t *dir = P.dir + B.dir_off + (size_t)lane * 4;
     const uint64_t o1 = live ? P.s1_off[p] : 0, o2 = live ? P.s2_off[p] : 0;
     const int cgs = (m + 3) / 4;
     const int front = ((n + R - 1) / R) * R - n;
@@ -439,8 +439,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     auto neighbour = [&](int c, uint32_t rho) { return c - ((int)(((uint32_t)c - rho + (uint32_t)off) & MASK) - off); };
     // residue words (4 columns) of row block `rb` (counted over the front-padded rows), column group cg
     auto block_words = [&](int rb, int cg) {
-        const int s = rb / WPC, w = rb % WPC;
-        return *reinterpret_cast<const uint4 *>(dir + ((size_t)s * cgs + cg) * (64 * CHW) + w * 4);
+        return *reinterpret_cast<const uint4 *>(dir + ((size_t)rb * cgs + cg) * 256);  // rb = strip * WPC + w
     };
 
     // end cell, its working-space score `cur`, and the reported score
