@@ -110,6 +110,9 @@ def main():
     pb_l = _native.PackedBatch(s1, o1, s2, o2, "local", table, code1, code2, 1, 1)
     plan_g = eng.plan(pb_g)
     plan_l = eng.plan(pb_l)
+    # both modes align the same pairs: the local pass reads the packed copy the global pass made
+    if os.environ.get("BIOALIGN_BENCH_SHARE_PACK", "1") != "0":
+        plan_l.share_pack(plan_g)
     cells_per_pass = plan_g.cells
     assert cells_per_pass == N * L * L
 

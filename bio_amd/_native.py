@@ -32,6 +32,7 @@ EXPORTS = (
     "bioalign_plan_workspace_bytes",
     "bioalign_plan_cells",
     "bioalign_plan_run",
+    "bioalign_plan_share_pack",
     "bioalign_plan_dp_ms",
 )
 
@@ -106,6 +107,8 @@ def lib():
         L.bioalign_plan_cells.argtypes = [C.c_void_p]
         L.bioalign_plan_run.restype = C.c_int
         L.bioalign_plan_run.argtypes = [C.c_void_p] + [C.c_void_p] * 9 + [C.c_void_p]
+        L.bioalign_plan_share_pack.restype = C.c_int
+        L.bioalign_plan_share_pack.argtypes = [C.c_void_p, C.c_void_p]
         L.bioalign_plan_dp_ms.restype = C.c_int
         L.bioalign_plan_dp_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         _lib = L
@@ -260,6 +263,14 @@ class Plan:
                                      d_t1, d_t2, d_t_off, d_t_len, stream)
         if rc != 0:
             self.engine._raise(rc)
+
+    def share_pack(self, packed_by: "Plan | None"):
+        """Read the packed sequence words `packed_by` (a plan of the same batch, other mode) makes instead of
+        packing again; every run of this plan must then follow a run of `packed_by` on the same stream."""
+        rc = lib().bioalign_plan_share_pack(self._h, packed_by._h if packed_by is not None else None)
+        if rc != 0:
+            self.engine._raise(rc)
+        self._packed_by = packed_by  # keeps it alive
 
     def dp_ms(self):
         """(summed ms, launches) of the DP kernel since the previous call; sync the stream first."""

@@ -90,6 +90,8 @@ struct bioalign_plan {
     int32_t *d_table = nullptr;
     uint32_t *d_wt = nullptr;
     uint32_t *d_s1w = nullptr, *d_s2w = nullptr;
+    const bioalign_plan *packed_by = nullptr;  // bioalign_plan_share_pack: read that plan's packed words
+    uint64_t lens_hash = 0;                    // of the pair lengths in batch order
     int32_t *d_hb = nullptr;
     uint32_t *d_dir = nullptr;
     void *d_rec = nullptr;  // move records of the linear-gap walk (16 bytes per 16 trace columns)
@@ -231,6 +233,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
                              (unsigned long long)p);
         len1[p] = (uint32_t)a;
         len2[p] = (uint32_t)b;
+        pl->lens_hash = (pl->lens_hash ^ (a * 0x9e3779b97f4a7c15ull + b)) * 0x100000001b3ull;
         max_n = std::max(max_n, a);
         max_m = std::max(max_m, b);
         min_nm_max = std::max(min_nm_max, std::min(a, b));
@@ -480,21 +483,25 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         return ctx->fail(BIOALIGN_EINVAL, "trace buffers are required unless BIOALIGN_SCORE_ONLY is set");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(ctx, hipSetDevice(ctx->devices[pl->device]));
+    uint32_t *const s1w = pl->packed_by ? pl->packed_by->d_s1w : pl->d_s1w;
+    uint32_t *const s2w = pl->packed_by ? pl->packed_by->d_s2w : pl->d_s2w;
     for (size_t c = 0; c < pl->chunks.size(); ++c) {
         const Chunk ch = pl->chunks[c];
-        BaPackParams pk;
-        pk.bundles = pl->d_bundles;
-        pk.bundle_begin = ch.bundle_begin;
-        pk.bundle_end = ch.bundle_end;
-        pk.perm = pl->d_perm;
-        pk.s1 = d_s1;
-        pk.s2 = d_s2;
-        pk.s1_off = d_s1_off;
-        pk.s2_off = d_s2_off;
-        pk.s1w = pl->d_s1w;
-        pk.s2w = pl->d_s2w;
-        pk.rows_per_strip = pl->R;
-        HIP_TRY(ctx, ba_launch_pack(pk, st));
+        if (!pl->packed_by) {
+            BaPackParams pk;
+            pk.bundles = pl->d_bundles;
+            pk.bundle_begin = ch.bundle_begin;
+            pk.bundle_end = ch.bundle_end;
+            pk.perm = pl->d_perm;
+            pk.s1 = d_s1;
+            pk.s2 = d_s2;
+            pk.s1_off = d_s1_off;
+            pk.s2_off = d_s2_off;
+            pk.s1w = s1w;
+            pk.s2w = s2w;
+            pk.rows_per_strip = pl->R;
+            HIP_TRY(ctx, ba_launch_pack(pk, st));
+        }
 
         const uint32_t nbun = ch.bundle_end - ch.bundle_begin;
         const int slices = pl->slices > 1 && nbun >= 4096 ? pl->slices : 1;
@@ -505,8 +512,8 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             dp.bundles = pl->d_bundles;
             dp.bundle_begin = b0;
             dp.bundle_end = b1;
-            dp.s1w = pl->d_s1w;
-            dp.s2w = pl->d_s2w;
+            dp.s1w = s1w;
+            dp.s2w = s2w;
             dp.hb = pl->d_hb;
             dp.dir = pl->d_dir;
             dp.best = pl->d_best;
@@ -551,8 +558,8 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             tr.table = pl->d_table;
             tr.na = pl->na;
             tr.nb = pl->nb;
-            tr.s1w = pl->d_s1w;
-            tr.s2w = pl->d_s2w;
+            tr.s1w = s1w;
+            tr.s2w = s2w;
             tr.hb = pl->d_hb;
             tr.dir = pl->d_dir;
             tr.best = pl->d_best;
@@ -581,6 +588,33 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
         }
     }
     pl->ran = true;
+    return 0;
+}
+
+extern "C" int bioalign_plan_share_pack(bioalign_plan *pl, const bioalign_plan *src)
+{
+    if (!pl) return BIOALIGN_EINVAL;
+    bioalign_ctx *ctx = pl->ctx;
+    if (!src || src == pl) {
+        pl->packed_by = nullptr;
+        return 0;
+    }
+    if (src->ctx != ctx || src->device != pl->device)
+        return ctx->fail(BIOALIGN_EINVAL, "share_pack: the plans belong to different contexts or devices");
+    if (src->packed_by) return ctx->fail(BIOALIGN_EINVAL, "share_pack: the other plan does not pack for itself");
+    if (src->n_pairs != pl->n_pairs || src->lens_hash != pl->lens_hash || src->R != pl->R ||
+        src->bundles.size() != pl->bundles.size())
+        return ctx->fail(BIOALIGN_EINVAL, "share_pack: the plans were not made for the same batch");
+    // one pass over the batch each: a chunked plan reuses its packed buffers from chunk to chunk
+    if (src->chunks.size() > 1 || pl->chunks.size() > 1)
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "share_pack: a plan runs in several chunks (BIOALIGN_WORKSPACE_BYTES)");
+    for (size_t b = 0; b < pl->bundles.size(); ++b) {
+        const BaBundle &x = pl->bundles[b], &y = src->bundles[b];
+        if (x.n != y.n || x.m != y.m || x.first != y.first || x.count != y.count || x.s1w_off != y.s1w_off ||
+            x.s2w_off != y.s2w_off)
+            return ctx->fail(BIOALIGN_EINVAL, "share_pack: the plans lay the batch out differently");
+    }
+    pl->packed_by = src;
     return 0;
 }
 

@@ -154,6 +154,18 @@ int bioalign_plan_run(bioalign_plan *plan, const uint8_t *d_s1, const uint64_t *
                       uint64_t *d_t_off, uint64_t *d_t_len, void *stream);
 
 /*
+ * Several modes over the SAME batch (the batched form of calling AlignGlobal and AlignLocal,
+ * align.go:76 / 152, or several AlignPair modes, align_pair.go:3, on the same pairs): a plan
+ * may read the packed copy of the sequences that another plan of the same batch has made
+ * instead of packing them again.  `plan` and `packed_by` must come from the same context and
+ * device and from batches with identical lengths (checked); from then on every
+ * bioalign_plan_run(plan, ...) must be queued on the same stream AFTER a run of `packed_by`
+ * on the same sequence bytes, and before `packed_by` runs on other bytes or is destroyed.
+ * packed_by == NULL makes the plan pack for itself again.
+ */
+int bioalign_plan_share_pack(bioalign_plan *plan, const bioalign_plan *packed_by);
+
+/*
  * Long mode: the same call shape as bioalign_batch, but every pair is aligned on its own by
  * the intra-sequence kernels -- rows spread over the lanes of many wavefronts, anti-diagonal
  * wavefront, strips pipelined through HBM -- which is what a single long pair needs

@@ -95,3 +95,37 @@ def test_limits_are_refused_not_computed_elsewhere():
         with pytest.raises(_native.BioAlignError) as e:
             fn()
         assert e.value.code == _native.EUNSUPPORTED
+
+
+def test_share_pack_between_modes():
+    # bioalign_plan_share_pack: the second mode's plan reads the packed sequences the first one made
+    import torch
+
+    s1, o1, s2, o2 = _ragged(2500, 21)
+    table, c1, c2 = synth.dna_table(1, -1)
+    eng = _native.Engine([0])
+    pbs = {m: _native.PackedBatch(s1, o1, s2, o2, m, table, c1, c2, 1, 1) for m in ("global", "local", "overlap")}
+    plans = {m: eng.plan(pb) for m, pb in pbs.items()}
+    plans["local"].share_pack(plans["global"])
+    plans["overlap"].share_pack(plans["global"])
+    dev = torch.device("cuda:0")
+    d = [torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(dev) for a in (s1, o1, s2, o2)]
+    N, cap = len(o1) - 1, pbs["global"].trace_capacity
+    for m in ("global", "local", "overlap"):  # the packing plan first, on one stream
+        sc = torch.empty(N, dtype=torch.int64, device=dev)
+        t1 = torch.zeros(cap + 16, dtype=torch.uint8, device=dev)
+        t2 = torch.zeros(cap + 16, dtype=torch.uint8, device=dev)
+        toff = torch.empty(N, dtype=torch.int64, device=dev)
+        tlen = torch.empty(N, dtype=torch.int64, device=dev)
+        plans[m].run(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), sc.data_ptr(), t1.data_ptr(),
+                     t2.data_ptr(), toff.data_ptr(), tlen.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = _traces((sc.cpu().numpy(), t1.cpu().numpy(), t2.cpu().numpy(), toff.cpu().numpy(), tlen.cpu().numpy()))
+        assert got == _traces(_batch(m, s1, o1, s2, o2, eng=eng)), m
+    # a plan of another batch is refused
+    s1b, o1b, s2b, o2b = _ragged(2500, 22)
+    other = eng.plan(_native.PackedBatch(s1b, o1b, s2b, o2b, "local", table, c1, c2, 1, 1))
+    with pytest.raises(Exception, match="same batch|differently"):
+        other.share_pack(plans["global"])
+    with pytest.raises(Exception, match="does not pack"):
+        other.share_pack(plans["local"])
