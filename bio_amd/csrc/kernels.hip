@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
 
     bool done = !live || (i == 0 && j == 0);
     // band bookkeeping, per lane: which row block each of the two LDS bands holds and its first column
-    int tag0 = -1, tag1 = -1, col00 = 0, col01 = 0;
+    int tag0 = -2, tag1 = -2, col00 = 0, col01 = 0;  // (group indices start at -1)
 
     // stage the band of row block rb that ends at the column group of column index `col` (0-based)
     auto load_band = [&](int which, int rb, int col) {
@@ -572,25 +572,34 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
         return (cg_hi - (BG - 1)) * 4;  // first column of the band
     };
 
-    // rows n .. 1.  The wavefront moves ROW BLOCK by row block (F rows: one residue word), top block
-    // index in an SGPR; inside a block every lane takes one move per round, whatever row it is in, until
-    // all lanes have left the block upwards (or are finished).  Rounds per block = the longest stretch of
-    // path any lane has inside it.
+    // rows n .. 1.  The wavefront moves GROUP by group of F rows, group index in an SGPR; inside a group
+    // every lane takes one move per round, whatever row it is in, until all lanes have left the group
+    // upwards (or are finished).  Rounds per group = the longest stretch of path any lane has inside it.
+    // A move out of row t (counted over the front-padded rows) reads rows t and t-1; group g holds the
+    // rows t with (t-1) / F == g, so that row t-1 always lies in row block g -- whose band every lane
+    // stages together when the wavefront enters the group (one wait per group for all lanes) -- and row t
+    // does too, except for the group's bottom row, which is row 0 of block g+1: the band of the
+    // previous group, still staged.
     constexpr int LOGF = (F == 16) ? 4 : (F == 8) ? 3 : 2;
     static_assert((1 << LOGF) == F, "F is 4, 8 or 16");
     int i_top = i;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) i_top = max(i_top, __shfl_xor(i_top, d));
-    i_top = __builtin_amdgcn_readfirstlane(i_top);  // uniform: the block loop's bookkeeping runs on the scalar unit
-    const int rb_first = front >> LOGF;             // the block that holds row 1
-    for (int rb = (i_top >= 1) ? ((i_top - 1 + front) >> LOGF) : -1; rb >= rb_first; --rb) {
-        const int sel = rb & 1;  // uniform: which LDS band belongs to this row block (the other one: the block above)
+    i_top = __builtin_amdgcn_readfirstlane(i_top);  // uniform: the group loop's bookkeeping runs on the scalar unit
+    const int g_last = (front - 1) >> LOGF;         // the group that holds row 1 (-1 when there is no padding: row 0 is never read)
+    for (int grp = (i_top >= 1) ? ((i_top - 2 + front) >> LOGF) : g_last - 1; grp >= g_last; --grp) {
+        const int sel = grp & 1;        // uniform: LDS band of row block grp; the other one holds block grp+1
+        const int rbm = max(grp, 0);    // (group -1: its band is never looked at)
+        if (!done && i >= 1 && j >= 1 && ((i - 2 + front) >> LOGF) == grp) {
+            const int c0 = load_band(sel, rbm, j - 1);
+            if (sel) { tag1 = grp; col01 = c0; } else { tag0 = grp; col00 = c0; }
+        }
         while (true) {
             const int t = i - 1 + front;  // my row, counted over the front-padded rows
-            const bool act = !done && i >= 1 && (t >> LOGF) == rb;
+            const bool act = !done && i >= 1 && ((t - 1) >> LOGF) == grp;
             if (!__any(act)) break;
             if (act) {
-                const int f = t & (F - 1);
+                const int f = t & (F - 1), fu = (t - 1) & (F - 1);
                 const uint32_t x_row = OPS ? 0u : sym1(i);  // s1[i-1]
                 if (j == 0) {
                     if (left_free) {
@@ -608,34 +617,30 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
                 } else if (MODE == BA_LOCAL && cur == 0) {
                     done = true;
                 } else {
-                    // bands: the current row block, and the one above while f == 0
                     const int cl = max(j - 2, 0);  // leftmost column index (0-based) this step reads
-                    int tagc = sel ? tag1 : tag0, colc = sel ? col01 : col00;
-                    if (tagc != rb || cl < colc) {
-                        colc = load_band(sel, rb, j - 1);
-                        tagc = rb;
-                        if (sel) { tag1 = tagc; col01 = colc; } else { tag0 = tagc; col00 = colc; }
+                    int tagm = sel ? tag1 : tag0, colm = sel ? col01 : col00;
+                    if (tagm != grp || cl < colm) {
+                        colm = load_band(sel, rbm, j - 1);
+                        tagm = grp;
+                        if (sel) { tag1 = tagm; col01 = colm; } else { tag0 = tagm; col00 = colm; }
                     }
-                    const uint32_t *bc = band + (size_t)sel * BW * 64;
-                    const uint32_t A = bc[(j - 1 - colc) * 64];
-                    const uint32_t Bw = bc[(cl - colc) * 64];
-                    uint32_t r_up, r_diag;
-                    if (f == 0 && i > 1) {  // row i-1 lies in row block rb-1
+                    const uint32_t *bm = band + (size_t)sel * BW * 64;
+                    const uint32_t A = bm[(j - 1 - colm) * 64];
+                    const uint32_t Bw = bm[(cl - colm) * 64];
+                    const uint32_t r_up = (A >> (fu * K)) & MASK;
+                    const uint32_t r_diag = (Bw >> (fu * K)) & MASK;
+                    uint32_t r_left;
+                    if (f == 0) {  // my row is row 0 of row block grp+1
                         int taga = sel ? tag0 : tag1, cola = sel ? col00 : col01;
-                        if (taga != rb - 1 || cl < cola) {
-                            cola = load_band(sel ^ 1, rb - 1, j - 1);
-                            taga = rb - 1;
+                        if (taga != grp + 1 || cl < cola) {
+                            cola = load_band(sel ^ 1, grp + 1, j - 1);
+                            taga = grp + 1;
                             if (sel) { tag0 = taga; col00 = cola; } else { tag1 = taga; col01 = cola; }
                         }
-                        const uint32_t *ba = band + (size_t)(sel ^ 1) * BW * 64;
-                        r_up = (ba[(j - 1 - cola) * 64] >> ((F - 1) * K)) & MASK;
-                        r_diag = (ba[(cl - cola) * 64] >> ((F - 1) * K)) & MASK;
+                        r_left = band[((size_t)(sel ^ 1) * BW + (cl - cola)) * 64] & MASK;
                     } else {
-                        const int shu = (f > 0 ? f - 1 : 0) * K;
-                        r_up = (A >> shu) & MASK;
-                        r_diag = (Bw >> shu) & MASK;
+                        r_left = (Bw >> (f * K)) & MASK;
                     }
-                    const uint32_t r_left = (Bw >> (f * K)) & MASK;
                     int mv;  // 0 up, 1 left, 2 diagonal
                     if (MODE == BA_LOCAL) {
                         // cur = max(0, up - g, left - g, diag + w) > 0 here, skip-prefix first, then up > left >
