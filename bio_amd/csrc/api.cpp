@@ -23,7 +23,7 @@ extern "C" size_t ba_dp_linear_lds_bytes(int nb, int nb4, int na_pad, int R, int
 extern "C" hipError_t ba_launch_pack(const BaPackParams &P, hipStream_t st);
 extern "C" hipError_t ba_launch_dp_linear(const BaDpParams &P, int mode, int R, int K, int waves, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_linear(const BaTraceParams &P, int mode, int R, int K, hipStream_t st);
-extern "C" size_t ba_dp_affine_lds_bytes(int nb, int nb4, int na_pad, int R, int waves);
+extern "C" size_t ba_dp_affine_lds_bytes(int nb, int nb4, int na_pad, int R, int waves, int nib);
 extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, int waves, int pipe, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_affine(const BaTraceParams &P, int mode, int R, hipStream_t st);
 
@@ -80,6 +80,7 @@ struct bioalign_plan {
     int R = 32, waves = 4;
     int pipe = 0;  // affine: one block per bundle, strips pipelined over its waves (kernels_affine.hip)
     int K = 2;  // residue bits per cell in the traceback matrix
+    int nib = 0, kappa = 0;  // affine, large alphabets: 4-bit strip profile (kernels_affine.hip)
     uint64_t cells = 0;
     std::vector<BaBundle> bundles;
     std::vector<Chunk> chunks;
@@ -244,8 +245,8 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
 
     // int8 profile with the bias folded in (kernels.hip: biased score space)
     // (affine: every level is biased by ext*(i+j) and the strip keeps H' - (open - ext), kernels_affine.hip)
-    const int bias = pl->affine ? pl->gap_open + pl->gap_ext : (pl->mode == BIOALIGN_LOCAL) ? pl->gap : 2 * pl->gap;
-    int wmax = 0;
+    int bias = pl->affine ? pl->gap_open + pl->gap_ext : (pl->mode == BIOALIGN_LOCAL) ? pl->gap : 2 * pl->gap;
+    int wmax = 0, wmin = 0;
     for (int i = 0; i < pl->na * pl->nb; ++i) {
         const int64_t v = (int64_t)in->score_table[i] + bias;
         if (v < -127 || v > 127)
@@ -253,6 +254,20 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
                              "score %d with gap %d does not fit the int8 profile of the fast kernels",
                              in->score_table[i], pl->gap);
         wmax = std::max(wmax, in->score_table[i]);
+        wmin = std::min(wmin, in->score_table[i]);
+    }
+    // Affine gaps over a large alphabet (proteins): the strip profile of 16 rows x nb symbols is what limits the
+    // wavefronts per CU.  Where the scores span at most 16 values the profile keeps w - min(w) in 4 bits and the
+    // kernel adds kappa = min(w) + open + ext back with the diagonal.  The rows of the first strip that lie above
+    // the matrix must score `open` (free top row; kernels_affine.hip): nibble open - kappa = -min(w) - ext.
+    int nib_pad = 0;
+    if (pl->affine && (pl->mode == BIOALIGN_LOCAL || pl->mode == BIOALIGN_FITTING) && pl->nb > 6 &&
+        wmax - wmin <= 15 && -wmin - pl->gap_ext >= 0 && -wmin - pl->gap_ext <= 15 &&
+        env_u64("BIOALIGN_NIBBLE_PROFILE", 1) != 0) {
+        pl->nib = 1;
+        pl->kappa = wmin + pl->gap_open + pl->gap_ext;
+        nib_pad = -wmin - pl->gap_ext;
+        bias = -wmin;
     }
     pl->nb4 = (pl->nb + 3) / 4;
     pl->na_pad = ((pl->na + 1 + 31) / 32) * 32;
@@ -354,13 +369,13 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
 
     // transposed int8 table: dword [c][a] = bytes score(a, 4c..4c+3) + bias; the padding
     // row (code na) and unused columns hold -128
-    std::vector<uint32_t> wt((size_t)pl->nb4 * pl->na_pad, 0x80808080u);
+    std::vector<uint32_t> wt((size_t)pl->nb4 * pl->na_pad, pl->nib ? 0u : 0x80808080u);
     for (int c = 0; c < pl->nb4; ++c)
         for (int a = 0; a < pl->na; ++a) {
             uint32_t w = 0;
             for (int q = 0; q < 4; ++q) {
                 const int b = 4 * c + q;
-                const int v = b < pl->nb ? in->score_table[a * pl->nb + b] + bias : -128;
+                const int v = b < pl->nb ? in->score_table[a * pl->nb + b] + bias : (pl->nib ? 0 : -128);
                 w |= (uint32_t)(uint8_t)(int8_t)v << (8 * q);
             }
             wt[(size_t)c * pl->na_pad + a] = w;
@@ -372,7 +387,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         for (int c = 0; c < pl->nb4; ++c) {
             uint32_t w = 0;
             for (int q = 0; q < 4; ++q) {
-                const int v = 4 * c + q < pl->nb ? pl->gap_open : -128;
+                const int v = pl->nib ? (4 * c + q < pl->nb ? nib_pad : 0) : (4 * c + q < pl->nb ? pl->gap_open : -128);
                 w |= (uint32_t)(uint8_t)(int8_t)v << (8 * q);
             }
             wt[(size_t)c * pl->na_pad + pl->na] = w;
@@ -395,23 +410,34 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     if (use_rec && (rc = dev_alloc(pl, &pl->d_rec, m_rec * 16))) return rc;
     if ((rc = dev_alloc(pl, (void **)&pl->d_best, (N ? N : 1) * sizeof(BaLocalBest)))) return rc;
     if (pl->affine) {
-        // Few bundles cannot fill 1024 SIMDs with one wavefront each: run the strips of a bundle
-        // as a pipeline over the waves of a block instead (as many waves as strips, up to 8).
+        // Run the strips of a bundle as a pipeline over the waves of a block (as many waves as strips, up to
+        // 8).  Few bundles: one wavefront each cannot fill 1024 SIMDs.  Many bundles: the row a strip hands
+        // to the next one is read back while it is still in the L2 instead of from HBM, and the smaller work
+        // units leave a shorter tail (1M protein pairs, 16-row strips: 1399 -> 1561 GCUPS; with the 32-row
+        // strips of small alphabets one wavefront per bundle stays ahead on large batches: 1752 vs 1404).
+        // BIOALIGN_PIPE_BELOW=<bundles> moves the batch size below which it is used (0: never).
         const int strips_max = (int)((max_n + R - 1) / R);
-        const uint64_t pipe_below = env_u64("BIOALIGN_PIPE_BELOW", 6144);
+        const uint64_t pipe_below = env_u64("BIOALIGN_PIPE_BELOW", R == 16 ? ~0ull : 6144);
         pl->pipe = strips_max >= 2 && pl->bundles.size() < pipe_below;
         if (pl->pipe) {
             pl->waves = std::min(8, std::max(2, strips_max));
-            while (pl->waves > 2 && ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, pl->waves) > 80 * 1024)
+            while (pl->waves > 2 && ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, pl->waves, pl->nib) > 80 * 1024)
                 --pl->waves;
             if ((max_m + 3) / 4 >= 65536) pl->pipe = 0;  // progress word: 16 bits of column groups
         }
         if (!pl->pipe) {
-            pl->waves = 4;
-            while (pl->waves > 1 && ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, pl->waves) > 40 * 1024)
-                pl->waves >>= 1;
+            // bundles per block: whatever puts the most wavefronts on a CU (160 KB of LDS, at most 16 resident here)
+            size_t best_waves_per_cu = 0;
+            for (int w = 4; w >= 1; w >>= 1) {
+                const size_t lds = ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, w, pl->nib);
+                const size_t per_cu = std::min<size_t>((160 * 1024) / lds * w, 16);
+                if (per_cu > best_waves_per_cu) {
+                    best_waves_per_cu = per_cu;
+                    pl->waves = w;
+                }
+            }
         }
-        if (ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, pl->waves) > 160 * 1024)
+        if (ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, pl->waves, pl->nib) > 160 * 1024)
             return ctx->fail(BIOALIGN_EUNSUPPORTED, "alphabet of %d column symbols needs more LDS than a CU has", pl->nb);
     }
     if (!pl->bundles.empty())
@@ -527,6 +553,8 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             dp.gap = pl->gap;
             dp.gap_open = pl->gap_open;
             dp.gap_ext = pl->gap_ext;
+            dp.nib = pl->nib;
+            dp.kappa = pl->kappa;
             const bool timed = pl->ev_used < pl->ev0.size();
             if (timed) HIP_TRY(ctx, hipEventRecord(pl->ev0[pl->ev_used], st));
             if (pl->affine)

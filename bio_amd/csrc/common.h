@@ -62,6 +62,8 @@ struct BaDpParams {
     int nb, nb4, na_pad;
     int gap;               // linear gap penalty (>= 0 on this path)
     int gap_open, gap_ext; // affine
+    int nib;               // affine, large alphabets: the strip profile holds 4-bit scores w - kappa0 (kernels_affine.hip)
+    int kappa;             // ... and this is added back with the diagonal: min(w) + open + ext
 };
 
 struct BaTraceParams {

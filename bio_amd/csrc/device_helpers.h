@@ -24,8 +24,10 @@ __device__ __forceinline__ uint32_t ba_push_residue(uint32_t acc, int x)
 // strip profile: prof[b][half][lane][16 rows] = score(row r of the strip, column symbol b), int8,
 // built from the transposed table wt[c][a] (dwords of 4 column symbols) in LDS.
 // Rows of the strip that lie above the matrix (t < front) take the padding code.
+// NIB: the table bytes are 0..15 and the profile keeps them as nibbles,
+// prof[b][half][lane][16 rows] in 8 bytes (row r of a half = nibble r): half the LDS.
 // ----------------------------------------------------------------------------
-template <int R>
+template <int R, bool NIB = false>
 __device__ __forceinline__ void ba_build_strip_profile(const uint32_t *wt, int nb, int nb4, int na_pad,
                                                        const uint8_t *code1, int pad_code,
                                                        const uint32_t (&aw)[R / 4], int s, int front,
@@ -58,9 +60,20 @@ __device__ __forceinline__ void ba_build_strip_profile(const uint32_t *wt, int n
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) {
                 const int b = 4 * c + bb;
-                if (b < nb)
-                    *reinterpret_cast<uint4 *>(prof_lane + (size_t)(b * HALVES + hf) * (64 * 16)) =
-                        make_uint4(o[bb][0], o[bb][1], o[bb][2], o[bb][3]);
+                if (b < nb) {
+                    if (NIB) {
+                        // bytes b0 b1 b2 b3 (each < 16) of a dword -> 16 bits b0 | b1 << 4 | b2 << 8 | b3 << 12
+                        auto nib4 = [](uint32_t x) {
+                            x = (x | (x >> 4)) & 0x00ff00ffu;
+                            return (x | (x >> 8)) & 0xffffu;
+                        };
+                        *reinterpret_cast<uint2 *>(prof_lane + (size_t)(b * HALVES + hf) * (64 * 8)) =
+                            make_uint2(nib4(o[bb][0]) | (nib4(o[bb][1]) << 16), nib4(o[bb][2]) | (nib4(o[bb][3]) << 16));
+                    } else {
+                        *reinterpret_cast<uint4 *>(prof_lane + (size_t)(b * HALVES + hf) * (64 * 16)) =
+                            make_uint4(o[bb][0], o[bb][1], o[bb][2], o[bb][3]);
+                    }
+                }
             }
         }
     }

@@ -50,10 +50,12 @@ __device__ __forceinline__ uint32_t ba_push_sign(uint32_t acc, int t)
 // v_max3 per cell:  key = (true score << key_shift) | (first row of its pair ? 1 : 0) << jbits | (jmax - j),
 // so the largest key of a row pair is its best cell, first in row-major order.
 // (klow0 / klow1: the low key bits for the even / odd rows of this column.)
-template <int MODE, int R>
+// NIB: pw holds 4-bit scores (row r = nibble r); the diagonal is hq + nibble + kappa (v_bfe_u32 + v_add3_u32).
+template <int MODE, int R, bool NIB>
 __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint32_t (&acc)[4], int (&rkey)[R / 2],
-                                                 const uint32_t (&pw)[R / 4], int top_hq, int &f, int &topdiag, int c,
-                                                 int ge, int fl, int key_shift, int klow0, int klow1)
+                                                 const uint32_t (&pw)[NIB ? R / 8 : R / 4], int top_hq, int &f,
+                                                 int &topdiag, int c, int ge, int fl, int key_shift, int klow0,
+                                                 int klow1, int kappa)
 {
     int up = top_hq, diag = topdiag;
     topdiag = top_hq;
@@ -65,7 +67,8 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
         acc[2] = ba_push_sign(acc[2], eo - en);
         const int fn = max(f, up);
         acc[3] = ba_push_sign(acc[3], f - fn);
-        const int d = diag + ba_sbyte(pw[r >> 2], r & 3);
+        const int d = NIB ? diag + (int)__builtin_amdgcn_ubfe(pw[NIB ? r >> 3 : 0], 4 * (r & 7), 4) + kappa
+                          : diag + ba_sbyte(pw[NIB ? 0 : r >> 2], r & 3);
         int H = ba_max3(en, fn, d);
         if (MODE == BA_LOCAL) {
             fl += ge;  // zero level of row r: ext*(i+j)
@@ -102,11 +105,15 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
 //                   a group of 4 columns once the strip above has handed over that group's
 //                   boundary row (written to global memory, announced through a progress
 //                   word in LDS).  W times as many wavefronts for batches of few, long pairs.
-template <int MODE, int R, bool PIPE>
+//
+// NIB: 4-bit strip profile (scores w - min(w), top-free modes, R == 16): an alphabet of 20 column symbols
+// takes 10 KB of LDS per wavefront instead of 20, which doubles the wavefronts a CU holds.
+template <int MODE, int R, bool PIPE, bool NIB>
 __global__ void __launch_bounds__(PIPE ? 512 : 256, BA_AFF_WPE) ba_dp_affine_kernel(BaDpParams P)
 {
     extern __shared__ __align__(16) uint32_t lds[];
     constexpr int HALVES = R / 16;
+    constexpr int PB = NIB ? 8 : 16;  // profile bytes per lane per (column symbol, 16 rows)
     constexpr int CPW = 32 / R;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -121,8 +128,8 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, BA_AFF_WPE) ba_dp_affine_ker
     const uint8_t *code1 = reinterpret_cast<const uint8_t *>(lds + wt_aligned);
     const uint8_t *code2 = code1 + 256;
     // PIPE: progress words, one per wave: (round << 16) | column groups handed over so far
-    volatile uint32_t *prog = lds + wt_aligned + 128 + (size_t)waves * P.nb * (HALVES * 64 * 4);
-    int32_t *combine = reinterpret_cast<int32_t *>(lds + wt_aligned + 128 + (size_t)waves * P.nb * (HALVES * 64 * 4) + 8);
+    volatile uint32_t *prog = lds + wt_aligned + 128 + (size_t)waves * P.nb * (HALVES * 64 * (PB / 4));
+    int32_t *combine = reinterpret_cast<int32_t *>(lds + wt_aligned + 128 + (size_t)waves * P.nb * (HALVES * 64 * (PB / 4)) + 8);
     if (PIPE && threadIdx.x < 8) prog[threadIdx.x] = 0;
     __syncthreads();
 
@@ -138,8 +145,9 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, BA_AFF_WPE) ba_dp_affine_ker
     constexpr bool top_free = (MODE == BA_LOCAL || MODE == BA_FITTING);
     constexpr bool left_free = (MODE == BA_LOCAL || MODE == BA_OVERLAP);
 
-    uint8_t *prof = reinterpret_cast<uint8_t *>(lds + wt_aligned + 128) + (size_t)wave * P.nb * (HALVES * 64 * 16);
-    uint8_t *prof_lane = prof + lane * 16;
+    uint8_t *prof = reinterpret_cast<uint8_t *>(lds + wt_aligned + 128) + (size_t)wave * P.nb * (HALVES * 64 * PB);
+    uint8_t *prof_lane = prof + lane * PB;
+    const int kappa = P.kappa;
 
     // the row a strip hands to the next one: (hq, F') per column, two buffers by strip parity
     int2 *bnd = reinterpret_cast<int2 *>(P.hb + B.hb_off) + lane;
@@ -195,7 +203,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, BA_AFF_WPE) ba_dp_affine_ker
         uint32_t aw[R / 4];
 #pragma unroll
         for (int q = 0; q < R / 4; ++q) aw[q] = s1w[(size_t)(s * (R / 4) + q) * 64];
-        ba_build_strip_profile<R>(lds, P.nb, P.nb4, P.na_pad, code1, P.pad_code, aw, s, front, prof_lane);
+        ba_build_strip_profile<R, NIB>(lds, P.nb, P.nb4, P.na_pad, code1, P.pad_code, aw, s, front, prof_lane);
 
         int hq[R], e[R], rkey[R / 2];
 #pragma unroll
@@ -237,23 +245,33 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, BA_AFF_WPE) ba_dp_affine_ker
             for (int q = 0; q < 4; ++q) {
                 if (FULL || jbase + q <= m) {
                     const int j = jbase + q;
-                    const uint4 *pp = reinterpret_cast<const uint4 *>(prof_lane + (size_t)bcode[q] * (HALVES * 64 * 16));
-                    uint32_t pw[R / 4];
+                    uint32_t pw[NIB ? R / 8 : R / 4];
+                    if (NIB) {
+                        const uint2 *pp = reinterpret_cast<const uint2 *>(prof_lane + (size_t)bcode[q] * (HALVES * 64 * 8));
 #pragma unroll
-                    for (int hf = 0; hf < HALVES; ++hf) {
-                        const uint4 v = pp[hf * 64];
-                        pw[hf * 4 + 0] = v.x;
-                        pw[hf * 4 + 1] = v.y;
-                        pw[hf * 4 + 2] = v.z;
-                        pw[hf * 4 + 3] = v.w;
+                        for (int hf = 0; hf < HALVES; ++hf) {
+                            const uint2 v = pp[hf * 64];
+                            pw[NIB ? hf * 2 + 0 : 0] = v.x;
+                            pw[NIB ? hf * 2 + 1 : 0] = v.y;
+                        }
+                    } else {
+                        const uint4 *pp = reinterpret_cast<const uint4 *>(prof_lane + (size_t)bcode[q] * (HALVES * 64 * 16));
+#pragma unroll
+                        for (int hf = 0; hf < HALVES; ++hf) {
+                            const uint4 v = pp[hf * 64];
+                            pw[NIB ? 0 : hf * 4 + 0] = v.x;
+                            pw[NIB ? 0 : hf * 4 + 1] = v.y;
+                            pw[NIB ? 0 : hf * 4 + 2] = v.z;
+                            pw[NIB ? 0 : hf * 4 + 3] = v.w;
+                        }
                     }
                     // the row above the strip: row 0 (F = -inf, align_affine.go:63-64) or the previous strip's last row
                     const int top_hq = (s == 0) ? row0(j) - c : in.b[q].x;
                     int f = (s == 0) ? BA_NEG : in.b[q].y;
                     int fl0 = ge * (i0 + j);  // local: zero level of the row above the strip
                     if (MODE == BA_LOCAL) asm volatile("v_mov_b32 %0, %1" : "=v"(fl0) : "s"(fl0));  // a per-lane chain, not 32 scalars
-                    ba_affine_column<MODE, R>(hq, e, acc, rkey, pw, top_hq, f, topdiag, c, ge, fl0, key_shift,
-                                              (1 << jbits) + (jmax - j), jmax - j);
+                    ba_affine_column<MODE, R, NIB>(hq, e, acc, rkey, pw, top_hq, f, topdiag, c, ge, fl0, key_shift,
+                                                   (1 << jbits) + (jmax - j), jmax - j, kappa);
                     if ((j - 1) % CPW == CPW - 1)
                         dirs[(size_t)((j - 1) / CPW) * 64] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
                     if (write_bnd) bnd_wr[(size_t)(j - 1) * 64] = make_int2(hq[R - 1], f);
@@ -523,21 +541,35 @@ __global__ void __launch_bounds__(256) ba_trace_affine_kernel(BaTraceParams P)
 extern "C" size_t ba_dp_linear_lds_bytes(int nb, int nb4, int na_pad, int R, int waves);
 
 // profile + tables as the linear kernel, plus the progress words and the best-cell exchange of PIPE
-extern "C" size_t ba_dp_affine_lds_bytes(int nb, int nb4, int na_pad, int R, int waves)
+// (nib: 4-bit profile, half the bytes)
+extern "C" size_t ba_dp_affine_lds_bytes(int nb, int nb4, int na_pad, int R, int waves, int nib)
 {
-    return ba_dp_linear_lds_bytes(nb, nb4, na_pad, R, waves) + (8 + (size_t)waves * 3 * 64) * 4;
+    const int wt_aligned = (nb4 * na_pad + 3) & ~3;
+    return (size_t)(wt_aligned + 128) * 4 + (size_t)waves * nb * (R / 16) * 64 * (nib ? 8 : 16) +
+           (8 + (size_t)waves * 3 * 64) * 4;
 }
 
 template <int MODE, int R>
 static hipError_t launch_dp_aff(const BaDpParams &P, int waves, int pipe, hipStream_t st)
 {
     const uint32_t nbundles = P.bundle_end - P.bundle_begin;
-    const size_t lds = ba_dp_affine_lds_bytes(P.nb, P.nb4, P.na_pad, R, waves);
+    const size_t lds = ba_dp_affine_lds_bytes(P.nb, P.nb4, P.na_pad, R, waves, P.nib);
+    const dim3 grid(pipe ? nbundles : (nbundles + waves - 1) / waves), block(waves * 64);
+    if (P.nib) {
+        // the 4-bit profile exists for the modes with a free top row and 16-row strips (api.cpp picks it)
+        if constexpr (R == 16 && (MODE == BA_LOCAL || MODE == BA_FITTING)) {
+            if (pipe)
+                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true, true>), grid, block, lds, st, P);
+            else
+                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false, true>), grid, block, lds, st, P);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    }
     if (pipe)
-        hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true>), dim3(nbundles), dim3(waves * 64), lds, st, P);
+        hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true, false>), grid, block, lds, st, P);
     else
-        hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false>), dim3((nbundles + waves - 1) / waves),
-                           dim3(waves * 64), lds, st, P);
+        hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false, false>), grid, block, lds, st, P);
     return hipGetLastError();
 }
 

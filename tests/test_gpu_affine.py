@@ -147,3 +147,33 @@ def test_affine_score_only_and_gap_symbol():
     finally:
         bio_amd.GapSymbol = ord("-")
         O.set_gap_symbol(ord("-"))
+
+
+@pytest.mark.parametrize("mode", ["local", "fitting"])
+@pytest.mark.parametrize("go,ge", [(11, 1), (7, 2), (9, 4)])
+def test_affine_protein_nibble_profile(mode, go, ge, monkeypatch):
+    # large alphabet + free top row: the strip profile holds 4-bit scores (kernels_affine.hip, NIB); both launch
+    # shapes (strips pipelined over the waves of a block / one wave per bundle) against the oracle and against
+    # the byte profile.  ge = 4 leaves the padding nibble exactly 0.
+    rng = random.Random(5)
+    alpha = b"ARNDCQEGHILKMFPSTWYV"
+    s1s = [bytes(rng.choice(alpha) for _ in range(rng.randrange(0, 90))) for _ in range(150)]
+    s2s = [bytes(rng.choice(alpha) for _ in range(rng.randrange(0, 90))) for _ in range(150)]
+    s1, o1, s2, o2 = synth.protein_pairs(64, 50, 47, config=3)
+    s1s += _seqs(s1, o1, 64)
+    s2s += _seqs(s2, o2, 64)
+    _check_affine(mode, s1s, s2s, bio_amd.Blosum62, O.Blosum62(), go, ge)
+    got = bio_amd.AlignAffineBatch(mode, s1s, s2s, bio_amd.Blosum62, go, ge)
+    monkeypatch.setenv("BIOALIGN_PIPE_BELOW", "0")
+    assert bio_amd.AlignAffineBatch(mode, s1s, s2s, bio_amd.Blosum62, go, ge) == got
+    monkeypatch.setenv("BIOALIGN_NIBBLE_PROFILE", "0")
+    assert bio_amd.AlignAffineBatch(mode, s1s, s2s, bio_amd.Blosum62, go, ge) == got
+
+
+def test_affine_pam250_keeps_the_byte_profile():
+    # Pam250 spans 26 values: no 4-bit profile; same answers as the oracle
+    rng = random.Random(6)
+    alpha = b"ARNDCQEGHILKMFPSTWYV"
+    s1s = [bytes(rng.choice(alpha) for _ in range(rng.randrange(1, 60))) for _ in range(100)]
+    s2s = [bytes(rng.choice(alpha) for _ in range(rng.randrange(1, 60))) for _ in range(100)]
+    _check_affine("local", s1s, s2s, bio_amd.Pam250, O.Pam250(), 10, 2)

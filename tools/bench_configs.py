@@ -17,6 +17,7 @@ ap.add_argument("--pairs", type=int, default=0)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--check", type=int, default=300)
 ap.add_argument("--linear", action="store_true", help="same shapes with a linear gap (gap = open)")
+ap.add_argument("--dna", action="store_true", help="config 3 shapes and penalties with a 4-letter alphabet (+1/-1): the LDS profile is 5x smaller")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 if args.config == 3:
@@ -24,6 +25,9 @@ if args.config == 3:
     s1, o1, s2, o2 = synth.protein_pairs(N, 300, 300, config=3)
     table, c1, c2 = score_table(Blosum62, np.unique(s1).tolist(), np.unique(s2).tolist())
     modes, go, ge = ["local"], 11, 1
+    if args.dna:
+        s1, o1, s2, o2 = synth.dna_pairs(N, 300, 300, config=3)
+        table, c1, c2 = synth.dna_table(1, -1)
 else:
     N = args.pairs or 12_500
     s1, o1, s2, o2 = synth.fitting_reads(N, 250, 2000, config=4)
@@ -54,7 +58,7 @@ for mode in modes:
            "dp_gcups": round(plan.cells / (ms / args.steps * 1e-3) / 1e9, 1), "workspace_gb": round(plan.workspace_bytes / 1e9, 2)}
     if args.check:
         from oracle import oracle as O
-        oa = O.Blosum62() if args.config == 3 else O.MatchAligner(1, -1)
+        oa = O.Blosum62() if (args.config == 3 and not args.dna) else O.MatchAligner(1, -1)
         k = min(args.check, N)
         sc = out["scores"][:k].cpu().numpy(); toff = out["t_off"][:k].cpu().numpy(); tlen = out["t_len"][:k].cpu().numpy()
         hi = int(o1[k] + o2[k]); t1 = out["t1"][:hi].cpu().numpy(); t2 = out["t2"][:hi].cpu().numpy()
