@@ -294,6 +294,9 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     }
     // strip height and block shape: the strip profile (nb * R bytes per lane) lives in LDS
     pl->R = (pl->nb <= 6 && pl->K <= 4) ? 32 : 16;
+    if (const uint64_t rows = env_u64("BIOALIGN_STRIP_ROWS", 0)) {  // experiments: 16 where 32 would be chosen
+        if (rows == 16) pl->R = 16;
+    }
     pl->waves = 4;
     while (pl->waves > 1 && ba_dp_linear_lds_bytes(pl->nb, pl->nb4, pl->na_pad, pl->R, pl->waves) > 40 * 1024)
         pl->waves >>= 1;
