@@ -13,6 +13,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -816,7 +817,7 @@ extern "C" int bioalign_batch(bioalign_ctx *ctx, const bioalign_batch_t *in, bio
 // long mode: one pair at a time on the intra-sequence wavefront kernels (kernels_long.hip)
 // ----------------------------------------------------------------------------
 extern "C" int ba_long_rows_per_lane(int K);
-extern "C" hipError_t ba_launch_long(const BaLongParams &P, int mode, int T, int K, hipStream_t st);
+extern "C" hipError_t ba_launch_long(const BaLongParams &P, int mode, int T, int K, int phases, hipStream_t st);
 
 namespace {
 
@@ -923,12 +924,18 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     P.t_len = reinterpret_cast<uint64_t *>(d_misc.as<uint8_t>() + 24);
     P.walk = reinterpret_cast<uint32_t *>(d_misc.as<uint8_t>() + 32);
     P.ops = d_ops.as<uint32_t>();
+    P.col0 = 0;  // the whole matrix on this device
+    P.left_col = nullptr;
+    P.right_col = nullptr;
+    P.start_i = 0;
+    P.start_j = -1;
+    P.scan_only = 0;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(ctx, hipEventCreate(&e0));
     HIP_TRY(ctx, hipEventCreate(&e1));
     HIP_TRY(ctx, hipEventRecord(e0, st));
-    hipError_t le = ba_launch_long(P, in->mode, T, K, st);
+    hipError_t le = ba_launch_long(P, in->mode, T, K, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK, st);
     if (le == hipSuccess) le = hipEventRecord(e1, st);
     uint64_t misc[8] = {0};
     if (le == hipSuccess) le = hipMemcpyAsync(misc, d_misc.p, 64, hipMemcpyDeviceToHost, st);
@@ -951,6 +958,222 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
         out->t_off[p] = slot + off;
         out->t_len[p] = len;
     }
+    return 0;
+}
+
+// ----------------------------------------------------------------------------
+// Long mode over column stripes: stripe g holds columns [c_g, c_g+1) of the matrix and all its
+// rows, on device g (mod the context's devices).  A stripe's column 0 is its left neighbour's last column:
+// n + 1 working-space scores, copied device to device (over xGMI between GPUs) once the neighbour's DP is
+// done.  Every stripe keeps its own residue words; the walk starts in the stripe that holds the end cell and
+// is handed on at each stripe's column 0 as one cell index; each stripe expands its own piece of the trace.
+// One 100k x 100k pair is latency-bound on ONE GPU already, so stripes buy capacity -- a
+// matrix whose residues do not fit one GPU's HBM -- not time.
+// ----------------------------------------------------------------------------
+struct Stripe {
+    int dev = 0;          // index into ctx->devices
+    uint64_t c0 = 0, m = 0, wps = 0;
+    DevBuf s1, s2, prof, c1, c2, bnd, flags, res, misc, t1, t2, ops, left, right;
+    hipStream_t st = nullptr;
+    hipEvent_t done = nullptr;
+    BaLongParams P;
+};
+
+int long_pair_striped(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *out, uint64_t p, int G,
+                      float *kernel_ms)
+{
+    const uint64_t a1 = in->s1_off[p], a2 = in->s2_off[p];
+    const uint64_t n = in->s1_off[p + 1] - a1, m = in->s2_off[p + 1] - a2;
+    const int g = in->gap_open;
+    const bool traces = !(in->flags & BIOALIGN_SCORE_ONLY);
+    if (in->nb > 4)
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode: at most 4 distinct column symbols (got %d)", in->nb);
+    int wmax = 0;
+    for (int i = 0; i < in->na * in->nb; ++i) {
+        const int64_t v = (int64_t)in->score_table[i] + 2 * g;
+        if (v < -127 || v > 127)
+            return ctx->fail(BIOALIGN_EUNSUPPORTED, "score %d with gap %d does not fit the int8 row profile",
+                             in->score_table[i], g);
+        wmax = std::max(wmax, in->score_table[i]);
+    }
+    const int64_t span = std::max<int64_t>((int64_t)wmax + 2 * (int64_t)g, 0) + 1;
+    const int K = span <= 4 ? 2 : span <= 16 ? 4 : span <= 256 ? 8 : 0;
+    if (!K) return ctx->fail(BIOALIGN_EUNSUPPORTED, "score span %lld does not fit 8 residue bits", (long long)span);
+    if ((n + m + 2) * 128 >= (1ull << 31))
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "pair too long for 32-bit working scores");
+    const int T = ba_long_rows_per_lane(K);
+    const int cpd = 32 / (T * K);
+    const uint64_t rs = 64ull * T;
+    const uint64_t strips = (n + rs - 1) / rs;
+    G = (int)std::min<uint64_t>((uint64_t)G, m);
+
+    std::vector<uint32_t> rowprof(in->na + 1, 0x80808080u);
+    for (int a = 0; a < in->na; ++a) {
+        uint32_t w = 0;
+        for (int b = 0; b < 4; ++b) {
+            const int v = b < in->nb ? in->score_table[a * in->nb + b] + 2 * g : -128;
+            w |= (uint32_t)(uint8_t)(int8_t)v << (8 * b);
+        }
+        rowprof[a] = w;
+    }
+
+    const int D = (int)ctx->devices.size();
+    std::vector<Stripe> S(G);
+    struct Cleanup {
+        std::vector<Stripe> &S;
+        bioalign_ctx *ctx;
+        ~Cleanup()
+        {
+            for (Stripe &x : S) {
+                (void)hipSetDevice(ctx->devices[x.dev]);
+                if (x.done) (void)hipEventDestroy(x.done);
+                if (x.st) (void)hipStreamDestroy(x.st);
+            }
+        }
+    } cleanup{S, ctx};
+    int rc;
+    for (int q = 0; q < G; ++q) {
+        Stripe &x = S[q];
+        x.dev = q % D;
+        x.c0 = m * (uint64_t)q / G;
+        x.m = m * (uint64_t)(q + 1) / G - x.c0;
+        x.wps = (x.m + 63 + cpd - 1) / cpd;
+        HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&x.st, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&x.done, hipEventDisableTiming));
+        const uint64_t cap = n + x.m;
+        if ((rc = x.s1.alloc(ctx, n + 16)) || (rc = x.s2.alloc(ctx, x.m + 16)) || (rc = x.prof.alloc(ctx, rowprof.size() * 4)) ||
+            (rc = x.c1.alloc(ctx, 256)) || (rc = x.c2.alloc(ctx, 256)) || (rc = x.bnd.alloc(ctx, strips * x.m * 4)) ||
+            (rc = x.flags.alloc(ctx, strips * 4 + 4)) || (rc = x.res.alloc(ctx, strips * x.wps * 256)) ||
+            (rc = x.misc.alloc(ctx, 64)) || (rc = x.left.alloc(ctx, (n + 1) * 4)) || (rc = x.right.alloc(ctx, (n + 1) * 4)))
+            return rc;
+        if (traces && ((rc = x.t1.alloc(ctx, cap + 32)) || (rc = x.t2.alloc(ctx, cap + 32)) ||
+                       (rc = x.ops.alloc(ctx, (cap / 16 + 2) * 4))))
+            return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(x.s1.p, in->s1 + a1, n, hipMemcpyHostToDevice, x.st));
+        HIP_TRY(ctx, hipMemcpyAsync(x.s2.p, in->s2 + a2 + x.c0, x.m, hipMemcpyHostToDevice, x.st));
+        HIP_TRY(ctx, hipMemcpyAsync(x.prof.p, rowprof.data(), rowprof.size() * 4, hipMemcpyHostToDevice, x.st));
+        HIP_TRY(ctx, hipMemcpyAsync(x.c1.p, in->code1, 256, hipMemcpyHostToDevice, x.st));
+        HIP_TRY(ctx, hipMemcpyAsync(x.c2.p, in->code2, 256, hipMemcpyHostToDevice, x.st));
+        HIP_TRY(ctx, hipMemsetAsync(x.flags.p, 0, strips * 4 + 4, x.st));
+        HIP_TRY(ctx, hipMemsetAsync(x.misc.p, 0, 64, x.st));
+        BaLongParams &P = x.P;
+        P.s1 = x.s1.as<uint8_t>();
+        P.s2 = x.s2.as<uint8_t>();
+        P.n = (uint32_t)n;
+        P.m = (uint32_t)x.m;
+        P.strips = (uint32_t)strips;
+        P.words_per_strip = (uint32_t)x.wps;
+        P.rowprof = x.prof.as<uint32_t>();
+        P.code1 = x.c1.as<uint8_t>();
+        P.code2 = x.c2.as<uint8_t>();
+        P.pad_code = in->na;
+        P.gap = g;
+        P.bnd = x.bnd.as<int32_t>();
+        P.flags = x.flags.as<uint32_t>();
+        P.resid = x.res.as<uint32_t>();
+        P.status = x.misc.as<uint32_t>();
+        P.table = nullptr;
+        P.nb = in->nb;
+        P.gap_symbol = in->gap_symbol;
+        P.score_only = 0;
+        P.score = reinterpret_cast<int64_t *>(x.misc.as<uint8_t>() + 8);
+        P.t1 = x.t1.as<uint8_t>();
+        P.t2 = x.t2.as<uint8_t>();
+        P.t_off = reinterpret_cast<uint64_t *>(x.misc.as<uint8_t>() + 16);
+        P.t_len = reinterpret_cast<uint64_t *>(x.misc.as<uint8_t>() + 24);
+        P.walk = reinterpret_cast<uint32_t *>(x.misc.as<uint8_t>() + 32);
+        P.ops = x.ops.as<uint32_t>();
+        P.col0 = (uint32_t)x.c0;
+        P.left_col = q > 0 ? x.left.as<int32_t>() : nullptr;
+        P.right_col = q + 1 < G ? x.right.as<int32_t>() : nullptr;
+        P.start_i = 0;
+        P.start_j = -1;
+        P.scan_only = 0;
+    }
+
+    const auto t_begin = std::chrono::steady_clock::now();
+    // DP, stripe after stripe: the neighbour's last column comes in over the device-to-device copy
+    for (int q = 0; q < G; ++q) {
+        Stripe &x = S[q];
+        HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
+        if (q > 0) {
+            Stripe &l = S[q - 1];
+            HIP_TRY(ctx, hipStreamWaitEvent(x.st, l.done, 0));
+            if (ctx->devices[l.dev] == ctx->devices[x.dev])
+                HIP_TRY(ctx, hipMemcpyAsync(x.left.p, l.right.p, (n + 1) * 4, hipMemcpyDeviceToDevice, x.st));
+            else
+                HIP_TRY(ctx, hipMemcpyPeerAsync(x.left.p, ctx->devices[x.dev], l.right.p, ctx->devices[l.dev], (n + 1) * 4, x.st));
+        }
+        hipError_t le = ba_launch_long(x.P, in->mode, T, K, BA_LONG_PHASE_DP, x.st);
+        if (le != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "long-mode DP kernel failed: %s", hipGetErrorString(le));
+        HIP_TRY(ctx, hipEventRecord(x.done, x.st));
+    }
+    // end cell: global = the last cell of the last stripe; fitting / overlap = leftmost strict maximum of the
+    // bottom row over all stripes (align_pair.go:169-182): every stripe reports its own
+    uint32_t misc[16];
+    int end_stripe = G - 1;
+    int64_t score = 0;
+    uint32_t start_i = (uint32_t)n, start_j = 0;
+    {
+        int32_t best = INT32_MIN;
+        for (int q = (in->mode == BIOALIGN_GLOBAL ? G - 1 : 0); q < G; ++q) {
+            Stripe &x = S[q];
+            HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
+            BaLongParams Pq = x.P;
+            Pq.scan_only = 1;
+            hipError_t le = ba_launch_long(Pq, in->mode, T, K, BA_LONG_PHASE_WALK, x.st);
+            if (le == hipSuccess) le = hipMemcpyAsync(misc, x.misc.p, 64, hipMemcpyDeviceToHost, x.st);
+            if (le == hipSuccess) le = hipStreamSynchronize(x.st);
+            if (le != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "long-mode kernels failed: %s", hipGetErrorString(le));
+            if (misc[0] != 0)
+                return ctx->fail(BIOALIGN_EHIP, "long mode: a strip gave up waiting for the strip above it (%u waits ran out)", misc[0]);
+            const int32_t v = (int32_t)misc[8 + 3];
+            if (v > best) {
+                best = v;
+                end_stripe = q;
+                start_i = misc[8 + 0];
+                start_j = misc[8 + 1];
+                score = (int64_t)misc[2] | ((int64_t)misc[3] << 32);
+            }
+        }
+    }
+    out->scores[p] = score;
+    if (traces) {
+        const uint64_t slot = a1 + a2, cap_total = n + m;
+        uint64_t pos_end = slot + cap_total, total = 0;
+        uint32_t i = start_i, j = start_j;
+        for (int q = end_stripe; q >= 0; --q) {
+            Stripe &x = S[q];
+            HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
+            BaLongParams Pq = x.P;
+            Pq.start_i = (int)i;
+            Pq.start_j = (int)j;
+            hipError_t le = ba_launch_long(Pq, in->mode, T, K, BA_LONG_PHASE_WALK, x.st);
+            if (le == hipSuccess) le = hipMemcpyAsync(misc, x.misc.p, 64, hipMemcpyDeviceToHost, x.st);
+            if (le == hipSuccess) le = hipStreamSynchronize(x.st);
+            if (le != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "long-mode kernels failed: %s", hipGetErrorString(le));
+            const uint64_t off = (uint64_t)misc[4] | ((uint64_t)misc[5] << 32), len = (uint64_t)misc[6] | ((uint64_t)misc[7] << 32);
+            if (off + len != n + x.m || len > pos_end - slot)
+                return ctx->fail(BIOALIGN_EHIP, "long mode: inconsistent trace extent in stripe %d", q);
+            if (len) {
+                HIP_TRY(ctx, hipMemcpy(out->t1 + pos_end - len, x.t1.as<uint8_t>() + off, len, hipMemcpyDeviceToHost));
+                HIP_TRY(ctx, hipMemcpy(out->t2 + pos_end - len, x.t2.as<uint8_t>() + off, len, hipMemcpyDeviceToHost));
+            }
+            pos_end -= len;
+            total += len;
+            i = misc[8 + 4];
+            j = misc[8 + 5];
+            if (q == 0) break;                                  // the first stripe ends every walk
+            if (i == 0 && in->mode == BIOALIGN_FITTING) break;  // free top row: the alignment ends there
+            if (j != 0) return ctx->fail(BIOALIGN_EHIP, "long mode: the walk left stripe %d inside it", q);
+            j = (uint32_t)S[q - 1].m;  // the same cell, as the left neighbour numbers it
+        }
+        out->t_off[p] = pos_end;
+        out->t_len[p] = total;
+    }
+    if (kernel_ms)
+        *kernel_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return 0;
 }
 
@@ -989,7 +1212,16 @@ extern "C" int bioalign_long(bioalign_ctx *ctx, const bioalign_batch_t *in, bioa
                 ctx->code = rc;
             }
         } else {
-            rc = long_pair(ctx, in, out, p, kernel_ms);
+            // column stripes over the context's devices when the residue words (K bits per cell, K <= 8) may not
+            // fit one device, or when BIOALIGN_LONG_STRIPES asks for them
+            int stripes = (int)env_u64("BIOALIGN_LONG_STRIPES", 0);
+            if (stripes == 0 && ctx->devices.size() > 1) {
+                size_t free_b = 0, total_b = 0;
+                HIP_TRY(ctx, hipSetDevice(ctx->devices[0]));
+                HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+                if ((double)n * (double)m > 0.8 * (double)free_b) stripes = (int)ctx->devices.size();
+            }
+            rc = stripes > 1 ? long_pair_striped(ctx, in, out, p, stripes, kernel_ms) : long_pair(ctx, in, out, p, kernel_ms);
         }
         if (rc) return rc;
     }

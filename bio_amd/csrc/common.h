@@ -96,6 +96,8 @@ struct BaTraceParams {
 //             lane l working on column t - l at step t (anti-diagonal skew)
 //   step    : one column per lane; residue words are stored by step, not by column
 // ----------------------------------------------------------------------------
+enum { BA_LONG_PHASE_DP = 1, BA_LONG_PHASE_WALK = 2 };
+
 struct BaLongParams {
     const uint8_t *s1, *s2;        // the pair's raw bytes (device)
     uint32_t n, m;
@@ -118,6 +120,14 @@ struct BaLongParams {
     uint8_t *t1, *t2;              // capacity n + m each, written right aligned
     uint64_t *t_off, *t_len;
     uint32_t *ops;                 // 2-bit move codes of the walk, 16 per dword, last column first
-    uint32_t *walk;                // [0], [1]: end cell (i, j); [2]: number of moves
+    uint32_t *walk;                // [0], [1]: cell the walk starts from (i, j); [2]: number of moves;
+                                   // [3]: true score of the end cell found (int32); [4], [5]: cell the walk stopped in
+    // column stripes (one matrix over several devices): this launch covers columns col0+1 .. col0+m of the matrix;
+    // n, m, s2, bnd, resid, ops, t1, t2 are the stripe's own.  All zero / null: the whole matrix.
+    uint32_t col0;                 // columns of the matrix left of this stripe
+    const int32_t *left_col;       // [n + 1] working-space scores Hs(i, col0), i = 0..n (null: the matrix' own column 0)
+    int32_t *right_col;            // [n + 1] out: Hs(i, col0 + m) (null: not wanted)
+    int start_i, start_j;          // walk: start from this cell instead of looking for the end cell (start_j < 0: look for it)
+    int scan_only;                 // walk: find the end cell of this stripe's bottom row, report it, stop
 };
 

@@ -94,6 +94,10 @@ __global__ void __launch_bounds__(64) ba_long_dp_kernel(BaLongParams P)
     const int i0 = n - (strips - s) * RS;
     const int b_top = (MODE == BA_FITTING) ? g : 0;   // Hs(0, j) = b_top * j
     const int b_left = (MODE == BA_OVERLAP) ? g : 0;  // Hs(i, 0) = b_left * i
+    // column stripes: my column 0 is column col0 of the matrix, handed over by the stripe to the left
+    const int col0 = (int)P.col0;
+    const int32_t *left_col = P.left_col;
+    auto first_col = [&](int i) { return left_col ? left_col[max(i, 0)] : b_left * max(i, 0); };
     int h[T];
     uint32_t prow[T];
 #pragma unroll
@@ -101,7 +105,7 @@ __global__ void __launch_bounds__(64) ba_long_dp_kernel(BaLongParams P)
         const int i = i0 + lane * T + r + 1;
         const int code = i >= 1 ? (int)P.code1[P.s1[i - 1]] : P.pad_code;
         prow[r] = P.rowprof[code];
-        h[r] = b_left * max(i, 0);
+        h[r] = first_col(i);
     }
     int32_t *bnd_out = P.bnd + (size_t)s * m;
     const int32_t *bnd_in = P.bnd + (size_t)(s > 0 ? s - 1 : 0) * m;
@@ -113,7 +117,7 @@ __global__ void __launch_bounds__(64) ba_long_dp_kernel(BaLongParams P)
     int bottom = h[T - 1];
     // score above my first row in the column BEFORE my current one (the diagonal of my first row);
     // before the first step that is column 0 of the row above: my upper neighbour's initial bottom
-    int topprev = ba_wave_shr1(b_left * max(i0, 0), bottom);
+    int topprev = ba_wave_shr1(first_col(i0), bottom);
     int bsym = 0;    // my current column's symbol code * 8
     int sreg = 0;    // column symbols of the current block of 64 steps, lane 0 reads its own
     int bin = 0;     // boundary row of the strip above for the same block
@@ -152,7 +156,7 @@ __global__ void __launch_bounds__(64) ba_long_dp_kernel(BaLongParams P)
         const bool steady = (t0 >= 63) && (t_end <= m);
         for (int t = t0; t < t_end; ++t) {
             // the row above my first row, in my current column: lane 0 takes the boundary
-            const int top_in = (s == 0) ? b_top * (t + 1) : bin;
+            const int top_in = (s == 0) ? b_top * (col0 + t + 1) : bin;
             const int top = ba_wave_shr1(top_in, bottom);
             bsym = ba_wave_shr1(sreg, bsym);
             if (steady) {
@@ -188,6 +192,15 @@ __global__ void __launch_bounds__(64) ba_long_dp_kernel(BaLongParams P)
         if (lane == 0) __hip_atomic_store(flag_out, BA_LONG_FINAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (failed && lane == 0) atomicAdd(P.status, 1u);
+    // column stripes: my last column is the next stripe's column 0
+    if (P.right_col) {
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            const int i = i0 + lane * T + r + 1;
+            if (i >= 1) P.right_col[i] = h[r];
+        }
+        if (s == 0 && lane == 0) P.right_col[0] = b_top * (col0 + m);
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -231,18 +244,29 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
     constexpr bool top_free = (MODE == BA_FITTING);
     constexpr bool left_free = (MODE == BA_OVERLAP);
     const int32_t *bottom_row = P.bnd + (size_t)(strips - 1) * m;
+    // column stripes: columns are the stripe's own (1..m), column 0 belongs to the stripe on the left
+    const int col0 = (int)P.col0;
+    const int32_t *left_col = P.left_col;
+    const bool first_stripe = (left_col == nullptr);
 
     // end cell (align.go:123-124; align_pair.go:169-182): n >= 1 and m >= 1 here
-    int i = n, j = m, cur;
-    if (MODE == BA_GLOBAL) {
+    int i = n, j = m, cur = 0, bv = 0;
+    if (P.start_j >= 0) {
+        // the walk comes in from the stripe on the right (or the host has chosen the end cell)
+        i = P.start_i;
+        j = P.start_j;
+    } else if (MODE == BA_GLOBAL) {
         cur = bottom_row[m - 1];
+        bv = cur - g * (n + col0 + m);
     } else {
         // leftmost strict maximum of the true scores Hs(n, j) - g*j of the bottom row, from column 0
-        int bv = b_left * n, bj = 0, bc = b_left * n;  // column 0
+        // (column 0 of the matrix only: a later stripe's column 0 is the last column of its neighbour)
+        int bj = 0, bc = b_left * n;
+        bv = first_stripe ? b_left * n : INT32_MIN;
         for (int c0 = 0; c0 < m; c0 += 64) {
             const int col = c0 + lane;  // 0-based array index = column col+1
             const int hv = col < m ? bottom_row[col] : 0;
-            int v = col < m ? hv - g * (col + 1) : INT32_MIN;
+            int v = col < m ? hv - g * (col0 + col + 1) : INT32_MIN;
             int jj = col + 1, cc = hv;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {  // wave argmax, smaller column wins ties
@@ -261,15 +285,22 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
         }
         j = bj;
         cur = bc;
+        bv = (bv == INT32_MIN) ? INT32_MIN : bv - g * n;  // true score H(n, j)
     }
+    i = __builtin_amdgcn_readfirstlane(i);
     j = __builtin_amdgcn_readfirstlane(j);
     cur = __builtin_amdgcn_readfirstlane(cur);
+    bv = __builtin_amdgcn_readfirstlane(bv);
     if (lane == 0) {
-        *P.score = (int64_t)cur - (int64_t)g * (i + j);
+        if (P.start_j < 0) *P.score = (int64_t)cur - (int64_t)g * (i + col0 + j);
         P.walk[0] = (uint32_t)i;  // where the walk starts
         P.walk[1] = (uint32_t)j;
+        P.walk[2] = 0;
+        P.walk[3] = (uint32_t)bv;
+        P.walk[4] = (uint32_t)i;
+        P.walk[5] = (uint32_t)j;
     }
-    if (P.score_only) return;
+    if (P.score_only || P.scan_only) return;
 
     // residue tiles
     int tile_s = -1, tile_u = 0;   // strip and first word index of `tile`
@@ -294,8 +325,8 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
     };
     // residue of cell (ii, jj), 0 <= ii <= n, 0 <= jj <= m
     auto residue = [&](int ii, int jj) -> uint32_t {
-        if (ii == 0) return (uint32_t)(b_top * jj) & MASK;   // Hs(0, j) = b_top * j
-        if (jj == 0) return (uint32_t)(b_left * ii) & MASK;  // Hs(i, 0) = b_left * i
+        if (ii == 0) return (uint32_t)(b_top * (col0 + jj)) & MASK;  // Hs(0, j) = b_top * j
+        if (jj == 0) return (uint32_t)(left_col ? left_col[ii] : b_left * ii) & MASK;  // Hs(i, 0) = b_left * i
         const int tt = ii - 1 + front;
         const int s = tt / RS, l = (tt % RS) / T, r = tt % T;
         const int t = (jj - 1) + l;
@@ -317,8 +348,8 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
 
     // The same lookup without loading anything: per-lane cell, says whether the staged tiles hold it
     auto peek = [&](int ii, int jj, bool &ok) -> uint32_t {
-        if (ii == 0) return (uint32_t)(b_top * jj) & MASK;
-        if (jj == 0) return (uint32_t)(b_left * ii) & MASK;
+        if (ii == 0) return (uint32_t)(b_top * (col0 + jj)) & MASK;
+        if (jj == 0) return (uint32_t)(left_col ? left_col[ii] : b_left * ii) & MASK;
         const int tt = ii - 1 + front;
         const int s = tt / RS, l = (tt % RS) / T, r = tt % T;
         const int t = (jj - 1) + l;
@@ -401,13 +432,22 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
                 --i;
         }
     }
-    // borders (align.go:92-100; align_pair.go:110-113, 158-159, 187-188)
-    if (!left_free && i > 0) emit_run(BA_MV_UP, (uint32_t)i);
-    if (!top_free && j > 0) emit_run(BA_MV_LEFT, (uint32_t)j);
+    // borders (align.go:92-100; align_pair.go:110-113, 158-159, 187-188).  A stripe that is not the first one
+    // hands the walk on at its column 0 (the left border is not its own); the top border is every stripe's.
+    if (first_stripe && !left_free && i > 0) {
+        emit_run(BA_MV_UP, (uint32_t)i);
+        i = 0;
+    }
+    if (!top_free && i == 0 && j > 0) {
+        emit_run(BA_MV_LEFT, (uint32_t)j);
+        j = 0;
+    }
     if (lane == 0) {
         if (fill > 0) ops[k >> 4] = (uint32_t)opacc;
         if (fill > 16) ops[(k >> 4) + 1] = (uint32_t)(opacc >> 32);
         P.walk[2] = k + fill;  // trace length
+        P.walk[4] = (uint32_t)i;  // where the walk stopped: (0, .) or (., 0) -- the next stripe's (i, its m)
+        P.walk[5] = (uint32_t)j;
     }
 }
 
@@ -476,7 +516,7 @@ __global__ void __launch_bounds__(1024) ba_long_expand_kernel(BaLongParams P)
 // launchers
 // ----------------------------------------------------------------------------
 template <int MODE, int T, int K>
-static hipError_t launch_long(const BaLongParams &P, hipStream_t st)
+static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
 {
     // 84 KB of (unused) dynamic LDS: at most one strip per CU, the placement the sc1 hand-off was measured in
     // (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads"); strips beyond the CU count queue up behind
@@ -484,35 +524,40 @@ static hipError_t launch_long(const BaLongParams &P, hipStream_t st)
     const size_t pad_lds = 84 * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
-    hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K>), dim3(P.strips), dim3(64), pad_lds, st, P);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ba_long_walk_kernel<MODE, T, K>), dim3(1), dim3(64), 0, st, P);
-    e = hipGetLastError();
-    if (e != hipSuccess || P.score_only) return e;
-    hipLaunchKernelGGL(ba_long_expand_kernel, dim3(1), dim3(1024), 0, st, P);
-    return hipGetLastError();
+    hipError_t e = hipSuccess;
+    if (phases & BA_LONG_PHASE_DP) {
+        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K>), dim3(P.strips), dim3(64), pad_lds, st, P);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (phases & BA_LONG_PHASE_WALK) {
+        hipLaunchKernelGGL((ba_long_walk_kernel<MODE, T, K>), dim3(1), dim3(64), 0, st, P);
+        if ((e = hipGetLastError()) != hipSuccess || P.score_only || P.scan_only) return e;
+        hipLaunchKernelGGL(ba_long_expand_kernel, dim3(1), dim3(1024), 0, st, P);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 template <int MODE>
-static hipError_t launch_long_mode(const BaLongParams &P, int T, int K, hipStream_t st)
+static hipError_t launch_long_mode(const BaLongParams &P, int T, int K, int phases, hipStream_t st)
 {
-    if (T == 8 && K == 2) return launch_long<MODE, 8, 2>(P, st);
-    if (T == 8 && K == 4) return launch_long<MODE, 8, 4>(P, st);
-    if (T == 4 && K == 8) return launch_long<MODE, 4, 8>(P, st);
+    if (T == 8 && K == 2) return launch_long<MODE, 8, 2>(P, phases, st);
+    if (T == 8 && K == 4) return launch_long<MODE, 8, 4>(P, phases, st);
+    if (T == 4 && K == 8) return launch_long<MODE, 4, 8>(P, phases, st);
     return hipErrorInvalidValue;
 }
 
 // rows per lane for a residue width: T * K divides 32
 extern "C" int ba_long_rows_per_lane(int K) { return K == 8 ? 4 : 8; }
 
-extern "C" hipError_t ba_launch_long(const BaLongParams &P, int mode, int T, int K, hipStream_t st)
+// phases: BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK (the walk includes the expansion of its moves into bytes)
+extern "C" hipError_t ba_launch_long(const BaLongParams &P, int mode, int T, int K, int phases, hipStream_t st)
 {
     if (P.n == 0 || P.m == 0 || P.strips == 0) return hipErrorInvalidValue;
     switch (mode) {
-    case BA_GLOBAL: return launch_long_mode<BA_GLOBAL>(P, T, K, st);
-    case BA_FITTING: return launch_long_mode<BA_FITTING>(P, T, K, st);
-    case BA_OVERLAP: return launch_long_mode<BA_OVERLAP>(P, T, K, st);
+    case BA_GLOBAL: return launch_long_mode<BA_GLOBAL>(P, T, K, phases, st);
+    case BA_FITTING: return launch_long_mode<BA_FITTING>(P, T, K, phases, st);
+    case BA_OVERLAP: return launch_long_mode<BA_OVERLAP>(P, T, K, phases, st);
     }
     return hipErrorInvalidValue;
 }

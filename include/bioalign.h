@@ -172,8 +172,11 @@ int bioalign_plan_share_pack(bioalign_plan *plan, const bioalign_plan *packed_by
  * (AlignGlobalLS, align_linear.go:9, on inputs the per-lane batch kernels would crawl through;
  * AlignPair "global" / "fitting" / "overlap", align_pair.go:3, likewise).  Linear gaps, at most
  * 4 distinct column symbols; anything else answers BIOALIGN_EUNSUPPORTED.  Runs on the first
- * device of the context.  kernel_ms (may be NULL) receives the summed DP + traceback kernel
- * time in milliseconds.
+ * device of the context -- unless the traceback matrix of a pair (up to one byte per cell) would
+ * not fit that device and the context holds several: the matrix is then cut into column
+ * stripes, one per device in turn, each stripe's last column handed to the next by a
+ * device-to-device copy (BIOALIGN_LONG_STRIPES=<count> forces a number of stripes).
+ * kernel_ms (may be NULL) receives the DP + traceback time in milliseconds.
  */
 int bioalign_long(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *out, float *kernel_ms);
 

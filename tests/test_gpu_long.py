@@ -70,3 +70,51 @@ def test_long_unsupported_fails_loudly():
     assert e.value.code == bio_amd._native.EUNSUPPORTED
     with pytest.raises(bio_amd._native.BioAlignError):
         bio_amd.AlignPairLong("global", b"ARNDC" * 10, b"ARNDCQ" * 10, bio_amd.Blosum62, 5)  # 6 column symbols
+
+
+@pytest.mark.parametrize("stripes", [2, 3, 5])
+@pytest.mark.parametrize("mode", ["global", "fitting", "overlap"])
+def test_long_column_stripes(mode, stripes, monkeypatch):
+    # the matrix cut into column stripes, every stripe with its own residues, the last column of a
+    # stripe handed to its right neighbour, the walk handed on at every stripe's column 0.  One GPU here, so all
+    # stripes sit on the same device (the copy between devices becomes a plain device copy); same answers.
+    monkeypatch.setenv("BIOALIGN_LONG_STRIPES", str(stripes))
+    a, oa = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
+    shapes = [(5, 7), (70, 64), (130, 129), (513, 190), (700, 900), (1100, 300), (30, 1000), (600, 3)]
+    for k, (n, m) in enumerate(shapes):
+        x, y = _pair(n, m, 700 + k)
+        assert bio_amd.AlignPairLong(mode, x, y, a, 1) == O.AlignPair(mode, x, y, oa, 1), (mode, stripes, n, m)
+
+
+def test_long_column_stripes_paths_along_the_borders(monkeypatch):
+    # walks that run along the top row / the left column across several stripes, and end cells in every stripe
+    monkeypatch.setenv("BIOALIGN_LONG_STRIPES", "4")
+    a, oa = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
+    rng = random.Random(3)
+    core = bytes(rng.choice(b"ACGT") for _ in range(150))
+    junk = lambda k: bytes(rng.choice(b"ACGT") for _ in range(k))
+    cases = [(core, junk(300) + core), (core, core + junk(300)), (core, junk(150) + core + junk(150)),
+             (junk(200) + core, core + junk(250)), (core + junk(200), junk(250) + core), (b"A" * 90, b"C" * 500),
+             (b"ACGT" * 30, b"ACGT" * 200)]
+    for x, y in cases:
+        for mode in ("global", "fitting", "overlap"):
+            assert bio_amd.AlignPairLong(mode, x, y, a, 1) == O.AlignPair(mode, x, y, oa, 1), (mode, len(x), len(y))
+    # other residue widths
+    a, oa = bio_amd.MatchAligner(5, -4), O.MatchAligner(5, -4)
+    x, y = _pair(900, 1300, 77)
+    for mode in ("global", "fitting", "overlap"):
+        assert bio_amd.AlignPairLong(mode, x, y, a, 3) == O.AlignPair(mode, x, y, oa, 3)
+
+
+def test_long_column_stripes_two_devices(monkeypatch):
+    # the same GPU listed twice: stripes alternate between two device entries of the context
+    from bio_amd import _native, pack_sequences, score_table
+    monkeypatch.setenv("BIOALIGN_LONG_STRIPES", "4")
+    x, y = _pair(1500, 2100, 88)
+    eng = _native.Engine([0, 0])
+    d1, o1 = pack_sequences([x]); d2, o2 = pack_sequences([y])
+    tbl, c1, c2 = score_table(bio_amd.MatchAligner(1, -1), np.unique(d1).tolist(), np.unique(d2).tolist())
+    pb = _native.PackedBatch(d1, o1, d2, o2, "global", tbl, c1, c2, gap_open=1, gap_extend=1)
+    scores, t1, t2, toff, tlen = eng.batch(pb, long=True)
+    a, b = int(toff[0]), int(toff[0] + tlen[0])
+    assert (int(scores[0]), t1[a:b].tobytes(), t2[a:b].tobytes()) == O.AlignPair("global", x, y, O.MatchAligner(1, -1), 1)
