@@ -34,6 +34,12 @@ EXPORTS = (
     "bioalign_plan_run",
     "bioalign_plan_share_pack",
     "bioalign_plan_dp_ms",
+    "bioalign_stripe_create",
+    "bioalign_stripe_destroy",
+    "bioalign_stripe_rows",
+    "bioalign_stripe_dp",
+    "bioalign_stripe_end_cell",
+    "bioalign_stripe_walk",
 )
 
 
@@ -109,6 +115,18 @@ def lib():
         L.bioalign_plan_run.argtypes = [C.c_void_p] + [C.c_void_p] * 9 + [C.c_void_p]
         L.bioalign_plan_share_pack.restype = C.c_int
         L.bioalign_plan_share_pack.argtypes = [C.c_void_p, C.c_void_p]
+        L.bioalign_stripe_create.restype = C.c_void_p
+        L.bioalign_stripe_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(Batch), C.c_uint64, C.c_uint64]
+        L.bioalign_stripe_destroy.argtypes = [C.c_void_p]
+        L.bioalign_stripe_rows.restype = C.c_uint64
+        L.bioalign_stripe_rows.argtypes = [C.c_void_p]
+        L.bioalign_stripe_dp.restype = C.c_int
+        L.bioalign_stripe_dp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bioalign_stripe_end_cell.restype = C.c_int
+        L.bioalign_stripe_end_cell.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]
+        L.bioalign_stripe_walk.restype = C.c_int
+        L.bioalign_stripe_walk.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.bioalign_plan_dp_ms.restype = C.c_int
         L.bioalign_plan_dp_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         _lib = L
@@ -279,3 +297,56 @@ class Plan:
         if rc != 0:
             self.engine._raise(rc)
         return ms.value, n.value
+
+
+class Stripe:
+    """Owns a bioalign_stripe: columns [col_begin, col_end) of the matrix of ONE long pair, on one device of the
+    engine (include/bioalign.h).  `pb` is a PackedBatch of exactly that pair."""
+
+    def __init__(self, engine: Engine, pb: PackedBatch, col_begin: int, col_end: int, device_index: int = 0):
+        self.engine = engine
+        self._pb = pb
+        self.col_begin, self.col_end = int(col_begin), int(col_end)
+        h = lib().bioalign_stripe_create(engine._h, device_index, C.byref(pb.c), self.col_begin, self.col_end)
+        if not h:
+            engine._raise(EINVAL)
+        self._h = C.c_void_p(h)
+        self.rows = int(lib().bioalign_stripe_rows(self._h))
+        self.width = self.col_end - self.col_begin
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().bioalign_stripe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def dp(self, d_left_col, d_right_col):
+        """Device addresses (ints or None) of rows+1 int32 each; returns when the stripe's DP is done."""
+        rc = lib().bioalign_stripe_dp(self._h, d_left_col, d_right_col)
+        if rc != 0:
+            self.engine._raise(rc)
+
+    def end_cell(self):
+        """(true score, column inside the stripe, score to report) of the end cell this stripe offers."""
+        v, j, sc = C.c_int64(), C.c_uint64(), C.c_int64()
+        rc = lib().bioalign_stripe_end_cell(self._h, C.byref(v), C.byref(j), C.byref(sc))
+        if rc != 0:
+            self.engine._raise(rc)
+        return v.value, j.value, sc.value
+
+    def walk(self, i: int, j_local: int):
+        """-> (piece of t1, piece of t2, exit_i, exit_j)"""
+        cap = self.rows + self.width + 1
+        t1 = np.zeros(cap, dtype=np.uint8)
+        t2 = np.zeros(cap, dtype=np.uint8)
+        ln, ei, ej = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        rc = lib().bioalign_stripe_walk(self._h, int(i), int(j_local), t1.ctypes.data, t2.ctypes.data,
+                                        C.byref(ln), C.byref(ei), C.byref(ej))
+        if rc != 0:
+            self.engine._raise(rc)
+        return t1[:ln.value].tobytes(), t2[:ln.value].tobytes(), ei.value, ej.value

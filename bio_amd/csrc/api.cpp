@@ -970,24 +970,37 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
 // One 100k x 100k pair is latency-bound on ONE GPU already, so stripes buy capacity -- a
 // matrix whose residues do not fit one GPU's HBM -- not time.
 // ----------------------------------------------------------------------------
-struct Stripe {
+}  // namespace
+
+// One column stripe of one pair on one device (also the C ABI's bioalign_stripe).
+struct bioalign_stripe {
+    bioalign_ctx *ctx = nullptr;
     int dev = 0;          // index into ctx->devices
-    uint64_t c0 = 0, m = 0, wps = 0;
+    int mode = 0, T = 8, K = 2;
+    uint64_t n = 0, c0 = 0, m = 0, m_total = 0, wps = 0, strips = 0;
+    bool traces = true, dp_done = false;
     DevBuf s1, s2, prof, c1, c2, bnd, flags, res, misc, t1, t2, ops, left, right;
     hipStream_t st = nullptr;
     hipEvent_t done = nullptr;
     BaLongParams P;
+    ~bioalign_stripe()
+    {
+        if (ctx) (void)hipSetDevice(ctx->devices[dev]);
+        if (done) (void)hipEventDestroy(done);
+        if (st) (void)hipStreamDestroy(st);
+    }
 };
 
-int long_pair_striped(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *out, uint64_t p, int G,
-                      float *kernel_ms)
+namespace {
+
+// geometry and checks shared by the long-mode paths
+int long_geometry(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t n, uint64_t m, int *K_out, int *T_out,
+                  std::vector<uint32_t> *rowprof)
 {
-    const uint64_t a1 = in->s1_off[p], a2 = in->s2_off[p];
-    const uint64_t n = in->s1_off[p + 1] - a1, m = in->s2_off[p + 1] - a2;
     const int g = in->gap_open;
-    const bool traces = !(in->flags & BIOALIGN_SCORE_ONLY);
     if (in->nb > 4)
-        return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode: at most 4 distinct column symbols (got %d)", in->nb);
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode packs the scores of one row symbol into one dword: "
+                                                "at most 4 distinct column symbols (got %d)", in->nb);
     int wmax = 0;
     for (int i = 0; i < in->na * in->nb; ++i) {
         const int64_t v = (int64_t)in->score_table[i] + 2 * g;
@@ -1001,176 +1014,235 @@ int long_pair_striped(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_re
     if (!K) return ctx->fail(BIOALIGN_EUNSUPPORTED, "score span %lld does not fit 8 residue bits", (long long)span);
     if ((n + m + 2) * 128 >= (1ull << 31))
         return ctx->fail(BIOALIGN_EUNSUPPORTED, "pair too long for 32-bit working scores");
-    const int T = ba_long_rows_per_lane(K);
-    const int cpd = 32 / (T * K);
-    const uint64_t rs = 64ull * T;
-    const uint64_t strips = (n + rs - 1) / rs;
-    G = (int)std::min<uint64_t>((uint64_t)G, m);
-
-    std::vector<uint32_t> rowprof(in->na + 1, 0x80808080u);
+    *K_out = K;
+    *T_out = ba_long_rows_per_lane(K);
+    rowprof->assign(in->na + 1, 0x80808080u);
     for (int a = 0; a < in->na; ++a) {
         uint32_t w = 0;
         for (int b = 0; b < 4; ++b) {
             const int v = b < in->nb ? in->score_table[a * in->nb + b] + 2 * g : -128;
             w |= (uint32_t)(uint8_t)(int8_t)v << (8 * b);
         }
-        rowprof[a] = w;
+        (*rowprof)[a] = w;
     }
+    return 0;
+}
 
-    const int D = (int)ctx->devices.size();
-    std::vector<Stripe> S(G);
-    struct Cleanup {
-        std::vector<Stripe> &S;
-        bioalign_ctx *ctx;
-        ~Cleanup()
-        {
-            for (Stripe &x : S) {
-                (void)hipSetDevice(ctx->devices[x.dev]);
-                if (x.done) (void)hipEventDestroy(x.done);
-                if (x.st) (void)hipStreamDestroy(x.st);
-            }
-        }
-    } cleanup{S, ctx};
-    int rc;
-    for (int q = 0; q < G; ++q) {
-        Stripe &x = S[q];
-        x.dev = q % D;
-        x.c0 = m * (uint64_t)q / G;
-        x.m = m * (uint64_t)(q + 1) / G - x.c0;
-        x.wps = (x.m + 63 + cpd - 1) / cpd;
-        HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&x.st, hipStreamNonBlocking));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&x.done, hipEventDisableTiming));
-        const uint64_t cap = n + x.m;
-        if ((rc = x.s1.alloc(ctx, n + 16)) || (rc = x.s2.alloc(ctx, x.m + 16)) || (rc = x.prof.alloc(ctx, rowprof.size() * 4)) ||
-            (rc = x.c1.alloc(ctx, 256)) || (rc = x.c2.alloc(ctx, 256)) || (rc = x.bnd.alloc(ctx, strips * x.m * 4)) ||
-            (rc = x.flags.alloc(ctx, strips * 4 + 4)) || (rc = x.res.alloc(ctx, strips * x.wps * 256)) ||
-            (rc = x.misc.alloc(ctx, 64)) || (rc = x.left.alloc(ctx, (n + 1) * 4)) || (rc = x.right.alloc(ctx, (n + 1) * 4)))
-            return rc;
-        if (traces && ((rc = x.t1.alloc(ctx, cap + 32)) || (rc = x.t2.alloc(ctx, cap + 32)) ||
-                       (rc = x.ops.alloc(ctx, (cap / 16 + 2) * 4))))
-            return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(x.s1.p, in->s1 + a1, n, hipMemcpyHostToDevice, x.st));
-        HIP_TRY(ctx, hipMemcpyAsync(x.s2.p, in->s2 + a2 + x.c0, x.m, hipMemcpyHostToDevice, x.st));
-        HIP_TRY(ctx, hipMemcpyAsync(x.prof.p, rowprof.data(), rowprof.size() * 4, hipMemcpyHostToDevice, x.st));
-        HIP_TRY(ctx, hipMemcpyAsync(x.c1.p, in->code1, 256, hipMemcpyHostToDevice, x.st));
-        HIP_TRY(ctx, hipMemcpyAsync(x.c2.p, in->code2, 256, hipMemcpyHostToDevice, x.st));
-        HIP_TRY(ctx, hipMemsetAsync(x.flags.p, 0, strips * 4 + 4, x.st));
-        HIP_TRY(ctx, hipMemsetAsync(x.misc.p, 0, 64, x.st));
-        BaLongParams &P = x.P;
-        P.s1 = x.s1.as<uint8_t>();
-        P.s2 = x.s2.as<uint8_t>();
-        P.n = (uint32_t)n;
-        P.m = (uint32_t)x.m;
-        P.strips = (uint32_t)strips;
-        P.words_per_strip = (uint32_t)x.wps;
-        P.rowprof = x.prof.as<uint32_t>();
-        P.code1 = x.c1.as<uint8_t>();
-        P.code2 = x.c2.as<uint8_t>();
-        P.pad_code = in->na;
-        P.gap = g;
-        P.bnd = x.bnd.as<int32_t>();
-        P.flags = x.flags.as<uint32_t>();
-        P.resid = x.res.as<uint32_t>();
-        P.status = x.misc.as<uint32_t>();
-        P.table = nullptr;
-        P.nb = in->nb;
-        P.gap_symbol = in->gap_symbol;
-        P.score_only = 0;
-        P.score = reinterpret_cast<int64_t *>(x.misc.as<uint8_t>() + 8);
-        P.t1 = x.t1.as<uint8_t>();
-        P.t2 = x.t2.as<uint8_t>();
-        P.t_off = reinterpret_cast<uint64_t *>(x.misc.as<uint8_t>() + 16);
-        P.t_len = reinterpret_cast<uint64_t *>(x.misc.as<uint8_t>() + 24);
-        P.walk = reinterpret_cast<uint32_t *>(x.misc.as<uint8_t>() + 32);
-        P.ops = x.ops.as<uint32_t>();
-        P.col0 = (uint32_t)x.c0;
-        P.left_col = q > 0 ? x.left.as<int32_t>() : nullptr;
-        P.right_col = q + 1 < G ? x.right.as<int32_t>() : nullptr;
-        P.start_i = 0;
-        P.start_j = -1;
-        P.scan_only = 0;
+// stripe of pair p of `in`: columns [c_begin, c_end) of the pair's matrix, all rows
+int stripe_init(bioalign_stripe &x, bioalign_ctx *ctx, int dev, const bioalign_batch_t *in, uint64_t p, uint64_t c_begin,
+                uint64_t c_end)
+{
+    const uint64_t a1 = in->s1_off[p], a2 = in->s2_off[p];
+    const uint64_t n = in->s1_off[p + 1] - a1, m = in->s2_off[p + 1] - a2;
+    if (n == 0 || c_begin >= c_end || c_end > m) return ctx->fail(BIOALIGN_EINVAL, "stripe: empty pair or column range");
+    std::vector<uint32_t> rowprof;
+    int rc = long_geometry(ctx, in, n, m, &x.K, &x.T, &rowprof);
+    if (rc) return rc;
+    x.ctx = ctx;
+    x.dev = dev;
+    x.mode = in->mode;
+    x.n = n;
+    x.m_total = m;
+    x.c0 = c_begin;
+    x.m = c_end - c_begin;
+    x.traces = !(in->flags & BIOALIGN_SCORE_ONLY);
+    const int cpd = 32 / (x.T * x.K);
+    const uint64_t rs = 64ull * x.T;
+    x.strips = (n + rs - 1) / rs;
+    x.wps = (x.m + 63 + cpd - 1) / cpd;
+    HIP_TRY(ctx, hipSetDevice(ctx->devices[dev]));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&x.st, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&x.done, hipEventDisableTiming));
+    const uint64_t cap = n + x.m;
+    if ((rc = x.s1.alloc(ctx, n + 16)) || (rc = x.s2.alloc(ctx, x.m + 16)) || (rc = x.prof.alloc(ctx, rowprof.size() * 4)) ||
+        (rc = x.c1.alloc(ctx, 256)) || (rc = x.c2.alloc(ctx, 256)) || (rc = x.bnd.alloc(ctx, x.strips * x.m * 4)) ||
+        (rc = x.flags.alloc(ctx, x.strips * 4 + 4)) || (rc = x.res.alloc(ctx, x.strips * x.wps * 256)) ||
+        (rc = x.misc.alloc(ctx, 64)) || (rc = x.left.alloc(ctx, (n + 1) * 4)) || (rc = x.right.alloc(ctx, (n + 1) * 4)))
+        return rc;
+    if (x.traces && ((rc = x.t1.alloc(ctx, cap + 32)) || (rc = x.t2.alloc(ctx, cap + 32)) ||
+                     (rc = x.ops.alloc(ctx, (cap / 16 + 2) * 4))))
+        return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(x.s1.p, in->s1 + a1, n, hipMemcpyHostToDevice, x.st));
+    HIP_TRY(ctx, hipMemcpyAsync(x.s2.p, in->s2 + a2 + x.c0, x.m, hipMemcpyHostToDevice, x.st));
+    HIP_TRY(ctx, hipMemcpyAsync(x.prof.p, rowprof.data(), rowprof.size() * 4, hipMemcpyHostToDevice, x.st));
+    HIP_TRY(ctx, hipMemcpyAsync(x.c1.p, in->code1, 256, hipMemcpyHostToDevice, x.st));
+    HIP_TRY(ctx, hipMemcpyAsync(x.c2.p, in->code2, 256, hipMemcpyHostToDevice, x.st));
+    HIP_TRY(ctx, hipMemsetAsync(x.flags.p, 0, x.strips * 4 + 4, x.st));
+    HIP_TRY(ctx, hipMemsetAsync(x.misc.p, 0, 64, x.st));
+    HIP_TRY(ctx, hipStreamSynchronize(x.st));  // rowprof is a local
+    BaLongParams &P = x.P;
+    P.s1 = x.s1.as<uint8_t>();
+    P.s2 = x.s2.as<uint8_t>();
+    P.n = (uint32_t)n;
+    P.m = (uint32_t)x.m;
+    P.strips = (uint32_t)x.strips;
+    P.words_per_strip = (uint32_t)x.wps;
+    P.rowprof = x.prof.as<uint32_t>();
+    P.code1 = x.c1.as<uint8_t>();
+    P.code2 = x.c2.as<uint8_t>();
+    P.pad_code = in->na;
+    P.gap = in->gap_open;
+    P.bnd = x.bnd.as<int32_t>();
+    P.flags = x.flags.as<uint32_t>();
+    P.resid = x.res.as<uint32_t>();
+    P.status = x.misc.as<uint32_t>();
+    P.table = nullptr;
+    P.nb = in->nb;
+    P.gap_symbol = in->gap_symbol;
+    P.score_only = 0;
+    P.score = reinterpret_cast<int64_t *>(x.misc.as<uint8_t>() + 8);
+    P.t1 = x.t1.as<uint8_t>();
+    P.t2 = x.t2.as<uint8_t>();
+    P.t_off = reinterpret_cast<uint64_t *>(x.misc.as<uint8_t>() + 16);
+    P.t_len = reinterpret_cast<uint64_t *>(x.misc.as<uint8_t>() + 24);
+    P.walk = reinterpret_cast<uint32_t *>(x.misc.as<uint8_t>() + 32);
+    P.ops = x.ops.as<uint32_t>();
+    P.col0 = (uint32_t)x.c0;
+    P.left_col = x.c0 > 0 ? x.left.as<int32_t>() : nullptr;
+    P.right_col = x.right.as<int32_t>();
+    P.start_i = 0;
+    P.start_j = -1;
+    P.scan_only = 0;
+    return 0;
+}
+
+// queues the stripe's DP on its stream; a stripe that is not the first one reads its left column (x.left) first
+int stripe_dp(bioalign_stripe &x)
+{
+    bioalign_ctx *ctx = x.ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
+    hipError_t le = ba_launch_long(x.P, x.mode, x.T, x.K, BA_LONG_PHASE_DP, x.st);
+    if (le != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "long-mode DP kernel failed: %s", hipGetErrorString(le));
+    HIP_TRY(ctx, hipEventRecord(x.done, x.st));
+    x.dp_done = true;
+    return 0;
+}
+
+// the end cell this stripe offers (align.go:123-124; align_pair.go:169-182): its true score, its column inside
+// the stripe, and the score to report if it is chosen.  Waits for the stripe's DP.
+int stripe_end_cell(bioalign_stripe &x, int64_t *true_score, uint64_t *j_local, int64_t *score)
+{
+    bioalign_ctx *ctx = x.ctx;
+    if (!x.dp_done) return ctx->fail(BIOALIGN_EINVAL, "stripe: end cell asked for before the DP");
+    HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
+    BaLongParams Pq = x.P;
+    Pq.scan_only = 1;
+    uint32_t misc[16];
+    hipError_t le = ba_launch_long(Pq, x.mode, x.T, x.K, BA_LONG_PHASE_WALK, x.st);
+    if (le == hipSuccess) le = hipMemcpyAsync(misc, x.misc.p, 64, hipMemcpyDeviceToHost, x.st);
+    if (le == hipSuccess) le = hipStreamSynchronize(x.st);
+    if (le != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "long-mode kernels failed: %s", hipGetErrorString(le));
+    if (misc[0] != 0)
+        return ctx->fail(BIOALIGN_EHIP, "long mode: a strip gave up waiting for the strip above it (%u waits ran out)", misc[0]);
+    *true_score = (int32_t)misc[8 + 3];
+    *j_local = misc[8 + 1];
+    *score = (int64_t)((uint64_t)misc[2] | ((uint64_t)misc[3] << 32));
+    return 0;
+}
+
+// walks from cell (i, j_local) to the stripe's border and expands the moves: the piece's bytes go to t1 / t2
+// (host, room for n + width each), its length to *len, the cell the walk stopped in to (*exit_i, *exit_j)
+int stripe_walk(bioalign_stripe &x, uint64_t i, uint64_t j_local, uint8_t *t1, uint8_t *t2, uint64_t *len_out,
+                uint64_t *exit_i, uint64_t *exit_j)
+{
+    bioalign_ctx *ctx = x.ctx;
+    if (!x.dp_done || !x.traces) return ctx->fail(BIOALIGN_EINVAL, "stripe: walk without DP or without trace buffers");
+    if (i > x.n || j_local > x.m) return ctx->fail(BIOALIGN_EINVAL, "stripe: start cell outside the stripe");
+    HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
+    BaLongParams Pq = x.P;
+    Pq.start_i = (int)i;
+    Pq.start_j = (int)j_local;
+    uint32_t misc[16];
+    hipError_t le = ba_launch_long(Pq, x.mode, x.T, x.K, BA_LONG_PHASE_WALK, x.st);
+    if (le == hipSuccess) le = hipMemcpyAsync(misc, x.misc.p, 64, hipMemcpyDeviceToHost, x.st);
+    if (le == hipSuccess) le = hipStreamSynchronize(x.st);
+    if (le != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "long-mode kernels failed: %s", hipGetErrorString(le));
+    const uint64_t off = (uint64_t)misc[4] | ((uint64_t)misc[5] << 32), len = (uint64_t)misc[6] | ((uint64_t)misc[7] << 32);
+    if (off + len != x.n + x.m) return ctx->fail(BIOALIGN_EHIP, "long mode: inconsistent trace extent in a stripe");
+    if (len) {
+        HIP_TRY(ctx, hipMemcpy(t1, x.t1.as<uint8_t>() + off, len, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(t2, x.t2.as<uint8_t>() + off, len, hipMemcpyDeviceToHost));
     }
+    *len_out = len;
+    *exit_i = misc[8 + 4];
+    *exit_j = misc[8 + 5];
+    return 0;
+}
+
+// after a stripe's walk stopped in (i, j): does the walk go on in the stripe to the left?
+bool walk_goes_on(int mode, uint64_t i) { return !(i == 0 && mode == BIOALIGN_FITTING); }  // free top row: it ends there
+
+int long_pair_striped(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *out, uint64_t p, int G,
+                      float *kernel_ms)
+{
+    const uint64_t a1 = in->s1_off[p], a2 = in->s2_off[p];
+    const uint64_t n = in->s1_off[p + 1] - a1, m = in->s2_off[p + 1] - a2;
+    const bool traces = !(in->flags & BIOALIGN_SCORE_ONLY);
+    G = (int)std::min<uint64_t>((uint64_t)G, m);
+    const int D = (int)ctx->devices.size();
+    std::vector<bioalign_stripe> S(G);
+    int rc;
+    for (int q = 0; q < G; ++q)
+        if ((rc = stripe_init(S[q], ctx, q % D, in, p, m * (uint64_t)q / G, m * (uint64_t)(q + 1) / G))) return rc;
 
     const auto t_begin = std::chrono::steady_clock::now();
     // DP, stripe after stripe: the neighbour's last column comes in over the device-to-device copy
     for (int q = 0; q < G; ++q) {
-        Stripe &x = S[q];
-        HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
+        bioalign_stripe &x = S[q];
         if (q > 0) {
-            Stripe &l = S[q - 1];
+            bioalign_stripe &l = S[q - 1];
+            HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
             HIP_TRY(ctx, hipStreamWaitEvent(x.st, l.done, 0));
             if (ctx->devices[l.dev] == ctx->devices[x.dev])
                 HIP_TRY(ctx, hipMemcpyAsync(x.left.p, l.right.p, (n + 1) * 4, hipMemcpyDeviceToDevice, x.st));
             else
                 HIP_TRY(ctx, hipMemcpyPeerAsync(x.left.p, ctx->devices[x.dev], l.right.p, ctx->devices[l.dev], (n + 1) * 4, x.st));
         }
-        hipError_t le = ba_launch_long(x.P, in->mode, T, K, BA_LONG_PHASE_DP, x.st);
-        if (le != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "long-mode DP kernel failed: %s", hipGetErrorString(le));
-        HIP_TRY(ctx, hipEventRecord(x.done, x.st));
+        if ((rc = stripe_dp(x))) return rc;
     }
     // end cell: global = the last cell of the last stripe; fitting / overlap = leftmost strict maximum of the
     // bottom row over all stripes (align_pair.go:169-182): every stripe reports its own
-    uint32_t misc[16];
     int end_stripe = G - 1;
-    int64_t score = 0;
-    uint32_t start_i = (uint32_t)n, start_j = 0;
-    {
-        int32_t best = INT32_MIN;
-        for (int q = (in->mode == BIOALIGN_GLOBAL ? G - 1 : 0); q < G; ++q) {
-            Stripe &x = S[q];
-            HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
-            BaLongParams Pq = x.P;
-            Pq.scan_only = 1;
-            hipError_t le = ba_launch_long(Pq, in->mode, T, K, BA_LONG_PHASE_WALK, x.st);
-            if (le == hipSuccess) le = hipMemcpyAsync(misc, x.misc.p, 64, hipMemcpyDeviceToHost, x.st);
-            if (le == hipSuccess) le = hipStreamSynchronize(x.st);
-            if (le != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "long-mode kernels failed: %s", hipGetErrorString(le));
-            if (misc[0] != 0)
-                return ctx->fail(BIOALIGN_EHIP, "long mode: a strip gave up waiting for the strip above it (%u waits ran out)", misc[0]);
-            const int32_t v = (int32_t)misc[8 + 3];
-            if (v > best) {
-                best = v;
-                end_stripe = q;
-                start_i = misc[8 + 0];
-                start_j = misc[8 + 1];
-                score = (int64_t)misc[2] | ((int64_t)misc[3] << 32);
-            }
+    int64_t score = 0, best = INT64_MIN;
+    uint64_t j = 0;
+    for (int q = (in->mode == BIOALIGN_GLOBAL ? G - 1 : 0); q < G; ++q) {
+        int64_t v, sc;
+        uint64_t jl;
+        if ((rc = stripe_end_cell(S[q], &v, &jl, &sc))) return rc;
+        if (v > best) {
+            best = v;
+            end_stripe = q;
+            j = jl;
+            score = sc;
         }
     }
     out->scores[p] = score;
     if (traces) {
-        const uint64_t slot = a1 + a2, cap_total = n + m;
-        uint64_t pos_end = slot + cap_total, total = 0;
-        uint32_t i = start_i, j = start_j;
+        const uint64_t slot = a1 + a2;
+        uint64_t pos_end = slot + n + m, total = 0, i = n;
+        std::vector<uint8_t> piece1, piece2;
         for (int q = end_stripe; q >= 0; --q) {
-            Stripe &x = S[q];
-            HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
-            BaLongParams Pq = x.P;
-            Pq.start_i = (int)i;
-            Pq.start_j = (int)j;
-            hipError_t le = ba_launch_long(Pq, in->mode, T, K, BA_LONG_PHASE_WALK, x.st);
-            if (le == hipSuccess) le = hipMemcpyAsync(misc, x.misc.p, 64, hipMemcpyDeviceToHost, x.st);
-            if (le == hipSuccess) le = hipStreamSynchronize(x.st);
-            if (le != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "long-mode kernels failed: %s", hipGetErrorString(le));
-            const uint64_t off = (uint64_t)misc[4] | ((uint64_t)misc[5] << 32), len = (uint64_t)misc[6] | ((uint64_t)misc[7] << 32);
-            if (off + len != n + x.m || len > pos_end - slot)
-                return ctx->fail(BIOALIGN_EHIP, "long mode: inconsistent trace extent in stripe %d", q);
-            if (len) {
-                HIP_TRY(ctx, hipMemcpy(out->t1 + pos_end - len, x.t1.as<uint8_t>() + off, len, hipMemcpyDeviceToHost));
-                HIP_TRY(ctx, hipMemcpy(out->t2 + pos_end - len, x.t2.as<uint8_t>() + off, len, hipMemcpyDeviceToHost));
-            }
+            bioalign_stripe &x = S[q];
+            piece1.resize(n + x.m + 1);
+            piece2.resize(n + x.m + 1);
+            uint64_t len = 0, ei = 0, ej = 0;
+            if ((rc = stripe_walk(x, i, j, piece1.data(), piece2.data(), &len, &ei, &ej))) return rc;
+            if (len > pos_end - slot) return ctx->fail(BIOALIGN_EHIP, "long mode: the pieces of the trace exceed its slot");
+            memcpy(out->t1 + pos_end - len, piece1.data(), len);
+            memcpy(out->t2 + pos_end - len, piece2.data(), len);
             pos_end -= len;
             total += len;
-            i = misc[8 + 4];
-            j = misc[8 + 5];
-            if (q == 0) break;                                  // the first stripe ends every walk
-            if (i == 0 && in->mode == BIOALIGN_FITTING) break;  // free top row: the alignment ends there
-            if (j != 0) return ctx->fail(BIOALIGN_EHIP, "long mode: the walk left stripe %d inside it", q);
-            j = (uint32_t)S[q - 1].m;  // the same cell, as the left neighbour numbers it
+            if (q == 0 || !walk_goes_on(in->mode, ei)) break;
+            if (ej != 0) return ctx->fail(BIOALIGN_EHIP, "long mode: the walk left stripe %d inside it", q);
+            i = ei;
+            j = S[q - 1].m;  // the same cell, as the left neighbour numbers it
         }
         out->t_off[p] = pos_end;
         out->t_len[p] = total;
+    }
+    for (int q = 0; q < G; ++q) {
+        HIP_TRY(ctx, hipSetDevice(ctx->devices[S[q].dev]));
+        HIP_TRY(ctx, hipStreamSynchronize(S[q].st));
     }
     if (kernel_ms)
         *kernel_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -1226,4 +1298,78 @@ extern "C" int bioalign_long(bioalign_ctx *ctx, const bioalign_batch_t *in, bioa
         if (rc) return rc;
     }
     return 0;
+}
+
+// ----------------------------------------------------------------------------
+// C ABI of one column stripe (include/bioalign.h): what a process that owns ONE GPU of a group needs to take
+// part in a long-mode alignment whose matrix is spread over the group (bio_amd/long_stripes.py drives it over
+// torch.distributed, boundary columns as RCCL send / recv).
+// ----------------------------------------------------------------------------
+extern "C" bioalign_stripe *bioalign_stripe_create(bioalign_ctx *ctx, int device_index, const bioalign_batch_t *in,
+                                                   uint64_t col_begin, uint64_t col_end)
+{
+    if (!ctx) return nullptr;
+    if (!in || in->n_pairs != 1 || !in->s1 || !in->s2 || !in->s1_off || !in->s2_off || !in->score_table || !in->code1 ||
+        !in->code2) {
+        ctx->fail(BIOALIGN_EINVAL, "stripe: a batch of exactly one pair with sequences, offsets, score table and code maps");
+        return nullptr;
+    }
+    if (device_index < 0 || device_index >= (int)ctx->devices.size()) {
+        ctx->fail(BIOALIGN_EINVAL, "device index %d out of range", device_index);
+        return nullptr;
+    }
+    if (in->mode != BIOALIGN_GLOBAL && in->mode != BIOALIGN_FITTING && in->mode != BIOALIGN_OVERLAP) {
+        ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode covers global, fitting and overlap");
+        return nullptr;
+    }
+    if (in->gap_open != in->gap_extend || in->gap_open < 0) {
+        ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode covers linear gaps with a non-negative penalty");
+        return nullptr;
+    }
+    if (in->na <= 0 || in->nb <= 0 || in->na > 255 || in->nb > 255) {
+        ctx->fail(BIOALIGN_EINVAL, "alphabet sizes must be in 1..255 (got %d, %d)", in->na, in->nb);
+        return nullptr;
+    }
+    bioalign_stripe *x = new bioalign_stripe;
+    if (stripe_init(*x, ctx, device_index, in, 0, col_begin, col_end) != 0) {
+        delete x;
+        return nullptr;
+    }
+    return x;
+}
+
+extern "C" void bioalign_stripe_destroy(bioalign_stripe *x) { delete x; }
+
+extern "C" uint64_t bioalign_stripe_rows(const bioalign_stripe *x) { return x ? x->n : 0; }
+
+extern "C" int bioalign_stripe_dp(bioalign_stripe *x, const int32_t *d_left_col, int32_t *d_right_col)
+{
+    if (!x) return BIOALIGN_EINVAL;
+    bioalign_ctx *ctx = x->ctx;
+    if ((x->c0 > 0) != (d_left_col != nullptr))
+        return ctx->fail(BIOALIGN_EINVAL, "stripe: the left column is required for every stripe but the first, and only there");
+    HIP_TRY(ctx, hipSetDevice(ctx->devices[x->dev]));
+    if (d_left_col)
+        HIP_TRY(ctx, hipMemcpyAsync(x->left.p, d_left_col, (x->n + 1) * 4, hipMemcpyDeviceToDevice, x->st));
+    int rc = stripe_dp(*x);
+    if (rc) return rc;
+    if (d_right_col)
+        HIP_TRY(ctx, hipMemcpyAsync(d_right_col, x->right.p, (x->n + 1) * 4, hipMemcpyDeviceToDevice, x->st));
+    HIP_TRY(ctx, hipStreamSynchronize(x->st));
+    return 0;
+}
+
+extern "C" int bioalign_stripe_end_cell(bioalign_stripe *x, int64_t *true_score, uint64_t *j_local, int64_t *score)
+{
+    if (!x) return BIOALIGN_EINVAL;
+    if (!true_score || !j_local || !score) return x->ctx->fail(BIOALIGN_EINVAL, "null argument");
+    return stripe_end_cell(*x, true_score, j_local, score);
+}
+
+extern "C" int bioalign_stripe_walk(bioalign_stripe *x, uint64_t i, uint64_t j_local, uint8_t *t1, uint8_t *t2,
+                                    uint64_t *len, uint64_t *exit_i, uint64_t *exit_j)
+{
+    if (!x) return BIOALIGN_EINVAL;
+    if (!t1 || !t2 || !len || !exit_i || !exit_j) return x->ctx->fail(BIOALIGN_EINVAL, "null argument");
+    return stripe_walk(*x, i, j_local, t1, t2, len, exit_i, exit_j);
 }

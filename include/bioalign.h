@@ -181,6 +181,36 @@ int bioalign_plan_share_pack(bioalign_plan *plan, const bioalign_plan *packed_by
 int bioalign_long(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *out, float *kernel_ms);
 
 /*
+ * One column stripe of a long-mode alignment, for a process that owns one GPU of a group
+ * (no counterpart in the reference; the stripes of bioalign_long, one at a time).  The pair's
+ * matrix is cut into column ranges [col_begin, col_end), one per process, left to right:
+ *   create      in = a batch of ONE pair (the whole s1 and the whole s2), linear gaps,
+ *               global / fitting / overlap; the stripe keeps what it needs on the device;
+ *   dp          d_left_col: device memory, rows()+1 int32 = the last column of the stripe on
+ *               the left in the kernels' working space (NULL for the stripe with col_begin 0);
+ *               d_right_col: device memory, rows()+1 int32, receives this stripe's last column
+ *               (may be NULL).  Returns when the stripe's DP is done;
+ *   end_cell    the end cell the stripe offers (align.go:123-124; align_pair.go:169-182): its
+ *               true score, its column inside the stripe (0 = the matrix' column 0, first stripe
+ *               only) and the score to report if it is the one chosen.  Global: ask the last
+ *               stripe; fitting / overlap: take the largest true score, leftmost stripe on ties;
+ *   walk        from cell (i, j_local) to the stripe's border: the piece of both gapped strings
+ *               (host memory, room for rows() + width each; a piece belongs in front of the
+ *               pieces of the stripes to its right), and the cell the walk stopped in.  The walk
+ *               goes on in the stripe on the left from (exit_i, that stripe's width) unless this
+ *               was the first stripe, or exit_i == 0 in fitting mode (free top row).
+ */
+typedef struct bioalign_stripe bioalign_stripe;
+bioalign_stripe *bioalign_stripe_create(bioalign_ctx *ctx, int device_index, const bioalign_batch_t *in,
+                                        uint64_t col_begin, uint64_t col_end);
+void bioalign_stripe_destroy(bioalign_stripe *stripe);
+uint64_t bioalign_stripe_rows(const bioalign_stripe *stripe);
+int bioalign_stripe_dp(bioalign_stripe *stripe, const int32_t *d_left_col, int32_t *d_right_col);
+int bioalign_stripe_end_cell(bioalign_stripe *stripe, int64_t *true_score, uint64_t *j_local, int64_t *score);
+int bioalign_stripe_walk(bioalign_stripe *stripe, uint64_t i, uint64_t j_local, uint8_t *t1, uint8_t *t2,
+                         uint64_t *len, uint64_t *exit_i, uint64_t *exit_j);
+
+/*
  * Timing hooks for the benchmark (no counterpart in the reference): the plan
  * records a pair of HIP events around every DP kernel launch, on the launch
  * stream, into a fixed pool of 256 pairs.  Once the stream has been
