@@ -218,6 +218,12 @@ def main():
             "frac": dom["frac"], "traffic": traffic,
             "note": "integer max-plus work: neither HBM nor MFMA bounds it (SURVEY.md 8d); "
                     f"HBM side for reference: direction words {dom['dir_write_gbs']} GB/s of {HBM_PEAK_GBS} GB/s peak",
+            # the HBM side of the same kernel: algorithmic bytes (K/8 per cell of residue words) and PMC-measured
+            # traffic per launch over the live launch duration, against the HBM peak
+            "hbm": {"algorithmic_bytes": dom["dir_bytes_per_pass"], "traffic": traffic,
+                    "achieved": round((traffic or dom["dir_bytes_per_pass"]) / (dom["pass_ms"] * 1e-3) / 1e9, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round((traffic or dom["dir_bytes_per_pass"]) / (dom["pass_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kern,
             "dp_kernel_share_of_step": round((ms_g + ms_l) / (elapsed * 1e3), 3),
         }
