@@ -321,9 +321,8 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     pl->chunks.clear();
     uint64_t o_s1w = 0, o_s2w = 0, o_hb = 0, o_dir = 0, o_rec = 0;
     uint64_t m_s1w = 0, m_s2w = 0, m_hb = 0, m_dir = 0, m_rec = 0;
-    // linear gaps: the walk records its moves and a second kernel expands them (kernels.hip); BIOALIGN_TRACE_BYTES=1
-    // keeps the older walk that writes the bytes itself
-    const bool use_rec = !pl->affine && !pl->score_only && env_u64("BIOALIGN_TRACE_BYTES", 0) == 0;
+    // linear gaps: the walk records its moves and a second kernel expands them (kernels.hip)
+    const bool use_rec = !pl->affine && !pl->score_only;
     uint32_t chunk_begin = 0;
     for (uint64_t q = 0; q < N;) {
         const uint32_t n = len1[perm[q]], m = len2[perm[q]];
@@ -835,6 +834,9 @@ struct DevBuf {
     T *as() const { return static_cast<T *>(p); }
 };
 
+int long_geometry(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t n, uint64_t m, int *K_out, int *T_out,
+                  std::vector<uint32_t> *rowprof);
+
 // one pair, n >= 1 and m >= 1, results into slot p of `out`
 int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *out, uint64_t p, float *dp_ms)
 {
@@ -842,37 +844,13 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     const uint64_t n = in->s1_off[p + 1] - a1, m = in->s2_off[p + 1] - a2;
     const int g = in->gap_open;
     const bool traces = !(in->flags & BIOALIGN_SCORE_ONLY);
-    if (in->nb > 4)
-        return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode packs the scores of one row symbol into one dword: "
-                                                "at most 4 distinct column symbols (got %d)", in->nb);
-    int wmax = 0;
-    for (int i = 0; i < in->na * in->nb; ++i) {
-        const int64_t v = (int64_t)in->score_table[i] + 2 * g;
-        if (v < -127 || v > 127)
-            return ctx->fail(BIOALIGN_EUNSUPPORTED, "score %d with gap %d does not fit the int8 row profile",
-                             in->score_table[i], g);
-        wmax = std::max(wmax, in->score_table[i]);
-    }
-    const int64_t span = std::max<int64_t>((int64_t)wmax + 2 * (int64_t)g, 0) + 1;
-    const int K = span <= 4 ? 2 : span <= 16 ? 4 : span <= 256 ? 8 : 0;
-    if (!K) return ctx->fail(BIOALIGN_EUNSUPPORTED, "score span %lld does not fit 8 residue bits", (long long)span);
-    if ((n + m + 2) * 128 >= (1ull << 31))
-        return ctx->fail(BIOALIGN_EUNSUPPORTED, "pair too long for 32-bit working scores");
-    const int T = ba_long_rows_per_lane(K);
+    int K = 0, T = 0;
+    std::vector<uint32_t> rowprof;
+    if (int rc0 = long_geometry(ctx, in, n, m, &K, &T, &rowprof)) return rc0;
     const int cpd = 32 / (T * K);
     const uint64_t rs = 64ull * T;
     const uint64_t strips = (n + rs - 1) / rs;
     const uint64_t wps = (m + 63 + cpd - 1) / cpd;
-
-    std::vector<uint32_t> rowprof(in->na + 1, 0x80808080u);
-    for (int a = 0; a < in->na; ++a) {
-        uint32_t w = 0;
-        for (int b = 0; b < 4; ++b) {
-            const int v = b < in->nb ? in->score_table[a * in->nb + b] + 2 * g : -128;
-            w |= (uint32_t)(uint8_t)(int8_t)v << (8 * b);
-        }
-        rowprof[a] = w;
-    }
 
     HIP_TRY(ctx, hipSetDevice(ctx->devices[0]));
     DevBuf d_s1, d_s2, d_prof, d_c1, d_c2, d_tab, d_bnd, d_flags, d_res, d_misc, d_t1, d_t2, d_ops;

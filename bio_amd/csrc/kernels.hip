@@ -404,12 +404,10 @@ struct BaMoveRec {
 };
 enum { BA_MV_UP = 0, BA_MV_LEFT = 1, BA_MV_DIAG = 2 };
 
-// OPS == false: the walk writes the two gapped byte strings itself (one lane = one pair,
-//               16-byte shift registers).
-// OPS == true : the walk only records its moves (BaMoveRec per 16 moves); ba_expand_kernel
-//               turns them into bytes with one thread per record -- no symbol load, no byte
-//               shuffling and no scattered store left on the walk's critical path.
-template <int MODE, int R, int K, bool OPS>
+// The walk only records its moves (BaMoveRec per 16 moves); ba_expand_kernel turns them into
+// bytes with one thread per record -- no symbol load, no byte shuffling and no scattered store
+// on the walk's critical path (a walk that wrote the bytes itself took 1.7 - 2 ms per mode).
+template <int MODE, int R, int K>
 __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
 {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -493,35 +491,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
 
     const uint64_t slot = o1 + o2;
     const uint64_t cap = (uint64_t)n + (uint64_t)m;
-    // sequence symbols come from the pack kernel's lane-interleaved raw words: a row is
-    // the same word index in every lane (one coalesced line per 4 rows); columns differ
-    // per lane but neighbouring lanes stay close
-    const uint32_t *s1w = P.s1w + B.s1w_off + lane;
-    const uint32_t *s2w = P.s2w + B.s2w_off + lane;
-    int k1_tag = -1, k2_tag = -1;
-    uint32_t x_word = 0, y_word = 0;
-    auto sym1 = [&](int i1) {  // s1[i1-1]
-        const int t = i1 - 1 + front;
-        if ((t >> 2) != k1_tag) {
-            k1_tag = t >> 2;
-            x_word = s1w[(size_t)k1_tag * 64];
-        }
-        return (x_word >> ((t & 3) * 8)) & 0xffu;
-    };
-    auto sym2 = [&](int j1) {  // s2[j1-1]
-        const int c = j1 - 1;
-        if ((c >> 2) != k2_tag) {
-            k2_tag = c >> 2;
-            y_word = s2w[(size_t)k2_tag * 64];
-            asm volatile("" : "+v"(y_word));  // keep the wait for the load inside this branch
-        }
-        return (y_word >> ((c & 3) * 8)) & 0xffu;
-    };
-    BaBackWriter w1, w2;
-    w1.init(P.t1, slot + cap);
-    w2.init(P.t2, slot + cap);
-    const uint32_t gs = P.gap_symbol;
-    // OPS: the record being filled
+    // the record being filled
     // (record 0 of a pair is a header for the expansion: trace length and end, so that it need not chase
     // perm -> t_len / t_off first)
     BaMoveRec *recs = reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap + 1;
@@ -600,17 +570,11 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
             if (!__any(act)) break;
             if (act) {
                 const int f = t & (F - 1), fu = (t - 1) & (F - 1);
-                const uint32_t x_row = OPS ? 0u : sym1(i);  // s1[i-1]
                 if (j == 0) {
                     if (left_free) {
                         done = true;
                     } else {  // left border of global / fitting: forced up move, Hs(i-1, 0) = 0
-                        if (OPS) {
-                            record(BA_MV_UP);
-                        } else {
-                            w1.put(x_row);
-                            w2.put(gs);
-                        }
+                        record(BA_MV_UP);
                         --i;
                         cur = 0;
                     }
@@ -666,12 +630,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
                         mv = (above_up && above_left) ? 2 : (above_up && !above_left) ? 1 : 0;
                         cur = (int)(mv == 2 ? rd : mv == 1 ? rl : ru);
                     }
-                    if (OPS) {
-                        record((uint32_t)mv);
-                    } else {
-                        w1.put(mv == 1 ? gs : x_row);
-                        w2.put(mv == 0 ? gs : sym2(j));
-                    }
+                    record((uint32_t)mv);
                     i -= (mv != 1);
                     j -= (mv != 0);
                 }
@@ -681,46 +640,33 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     // row 0: global / overlap walk left along the top border; local / fitting stop there
     if (!done && !top_free) {
         while (j > 0) {
-            if (OPS) {
-                record(BA_MV_LEFT);
-            } else {
-                w1.put(gs);
-                w2.put(sym2(j));
-            }
+            record(BA_MV_LEFT);
             --j;
         }
     }
     if (!live) return;
-    if (OPS) {
-        if (kq & 15u) {
-            BaMoveRec rr;
-            rr.ops = opw;
-            rr.i = rec_i;
-            rr.j = rec_j;
-            rr.count = kq & 15u;
-            recs[kq >> 4] = rr;
-        }
-        // Where the trace ends inside the pair's slot: at the slot's end, or -- whenever the slot
-        // has the room -- at the 16-byte boundary just below it, so that every full record of
-        // the expansion is one aligned 16-byte store.
-        const uint64_t len = kq;
-        const uint64_t mis = ((uint64_t)P.t1 + slot + cap) & 15u;
-        const uint64_t end = (mis + len <= cap) ? slot + cap - mis : slot + cap;
-        P.t_off[p] = end - len;
-        P.t_len[p] = len;
-        BaMoveRec hd;
-        hd.ops = (uint32_t)len;
-        hd.i = (uint32_t)end;
-        hd.j = (uint32_t)(end >> 32);
-        hd.count = p;
-        recs[-1] = hd;
-    } else {
-        w1.finish();
-        w2.finish();
-        const uint64_t len = (uint64_t)w1.length();
-        P.t_off[p] = slot + cap - len;
-        P.t_len[p] = len;
+    if (kq & 15u) {
+        BaMoveRec rr;
+        rr.ops = opw;
+        rr.i = rec_i;
+        rr.j = rec_j;
+        rr.count = kq & 15u;
+        recs[kq >> 4] = rr;
     }
+    // Where the trace ends inside the pair's slot: at the slot's end, or -- whenever the slot
+    // has the room -- at the 16-byte boundary just below it, so that every full record of
+    // the expansion is one aligned 16-byte store.
+    const uint64_t len = kq;
+    const uint64_t mis = ((uint64_t)P.t1 + slot + cap) & 15u;
+    const uint64_t end = (mis + len <= cap) ? slot + cap - mis : slot + cap;
+    P.t_off[p] = end - len;
+    P.t_len[p] = len;
+    BaMoveRec hd;
+    hd.ops = (uint32_t)len;
+    hd.i = (uint32_t)end;
+    hd.j = (uint32_t)(end >> 32);
+    hd.count = p;
+    recs[-1] = hd;
 }
 
 // Expansion of the walk's records into the two gapped byte strings (align.go:126-143, 224-248;
@@ -864,14 +810,11 @@ static hipError_t launch_trace(const BaTraceParams &P, hipStream_t st)
     const uint32_t nbundles = P.bundle_end - P.bundle_begin;
     const uint32_t blocks = (nbundles + waves - 1) / waves;
     const size_t lds = ba_trace_linear_lds_bytes(P.na, P.nb, R, K, waves);
-    if (P.rec && !P.score_only) {
-        hipLaunchKernelGGL((ba_trace_linear_kernel<MODE, R, K, true>), dim3(blocks), dim3(waves * 64), lds, st, P);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(ba_expand_kernel, dim3(nbundles), dim3(64 * BA_EXPAND_TPP), 0, st, P);
-    } else {
-        hipLaunchKernelGGL((ba_trace_linear_kernel<MODE, R, K, false>), dim3(blocks), dim3(waves * 64), lds, st, P);
-    }
+    if (!P.score_only && !P.rec) return hipErrorInvalidValue;  // the walk records its moves for the expansion
+    hipLaunchKernelGGL((ba_trace_linear_kernel<MODE, R, K>), dim3(blocks), dim3(waves * 64), lds, st, P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || P.score_only) return e;
+    hipLaunchKernelGGL(ba_expand_kernel, dim3(nbundles), dim3(64 * BA_EXPAND_TPP), 0, st, P);
     return hipGetLastError();
 }
 

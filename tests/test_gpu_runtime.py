@@ -56,15 +56,6 @@ def test_workspace_chunking(monkeypatch):
     assert _traces(_batch("global", s1, o1, s2, o2, go=4, ge=1)) == whole_affine
 
 
-@pytest.mark.parametrize("mode", ["global", "local", "overlap"])
-def test_fused_byte_writing_walk_matches(mode, monkeypatch):
-    # BIOALIGN_TRACE_BYTES=1: the older walk that writes the bytes itself (kernels.hip, OPS == false)
-    s1, o1, s2, o2 = _ragged(1500, 11)
-    ref = _traces(_batch(mode, s1, o1, s2, o2))
-    monkeypatch.setenv("BIOALIGN_TRACE_BYTES", "1")
-    assert _traces(_batch(mode, s1, o1, s2, o2)) == ref
-
-
 def test_sliced_two_stream_run_matches(monkeypatch):
     # BIOALIGN_SLICES: traceback of slice k on a second stream under the DP of slice k+1
     N = 64 * 4200
