@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -34,6 +35,17 @@ EXPORTS = (
     "bioalign_plan_run",
     "bioalign_plan_share_pack",
     "bioalign_plan_dp_ms",
+    "bioalign_fasta_parse",
+    "bioalign_fasta_destroy",
+    "bioalign_fasta_count",
+    "bioalign_fasta_bytes",
+    "bioalign_fasta_kernel_ms",
+    "bioalign_fasta_device_seq",
+    "bioalign_fasta_device_off",
+    "bioalign_fasta_off",
+    "bioalign_fasta_header_begin",
+    "bioalign_fasta_header_len",
+    "bioalign_fasta_copy_seq",
     "bioalign_stripe_create",
     "bioalign_stripe_destroy",
     "bioalign_stripe_rows",
@@ -91,6 +103,13 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950); "
                 "bio_amd has no CPU fallback"
             )
+        # PyTorch-ROCm ships its own HIP runtime: a process that initialises the system one first (through this
+        # library) and imports torch afterwards finds "No HIP GPUs" in torch.  Let torch load first when it is there.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         L.bioalign_abi_version.restype = C.c_int
         L.bioalign_create.restype = C.c_void_p
@@ -115,6 +134,20 @@ def lib():
         L.bioalign_plan_run.argtypes = [C.c_void_p] + [C.c_void_p] * 9 + [C.c_void_p]
         L.bioalign_plan_share_pack.restype = C.c_int
         L.bioalign_plan_share_pack.argtypes = [C.c_void_p, C.c_void_p]
+        L.bioalign_fasta_parse.restype = C.c_void_p
+        L.bioalign_fasta_parse.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int]
+        L.bioalign_fasta_destroy.argtypes = [C.c_void_p]
+        for fn in (L.bioalign_fasta_count, L.bioalign_fasta_bytes):
+            fn.restype = C.c_uint64
+            fn.argtypes = [C.c_void_p]
+        L.bioalign_fasta_kernel_ms.restype = C.c_float
+        L.bioalign_fasta_kernel_ms.argtypes = [C.c_void_p]
+        for fn in (L.bioalign_fasta_device_seq, L.bioalign_fasta_device_off, L.bioalign_fasta_off,
+                   L.bioalign_fasta_header_begin, L.bioalign_fasta_header_len):
+            fn.restype = C.c_void_p
+            fn.argtypes = [C.c_void_p]
+        L.bioalign_fasta_copy_seq.restype = C.c_int
+        L.bioalign_fasta_copy_seq.argtypes = [C.c_void_p, C.c_void_p]
         L.bioalign_stripe_create.restype = C.c_void_p
         L.bioalign_stripe_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(Batch), C.c_uint64, C.c_uint64]
         L.bioalign_stripe_destroy.argtypes = [C.c_void_p]
@@ -350,3 +383,54 @@ class Stripe:
         if rc != 0:
             self.engine._raise(rc)
         return t1[:ln.value].tobytes(), t2[:ln.value].tobytes(), ei.value, ej.value
+
+
+class Fasta:
+    """Owns a bioalign_fasta: FASTA text parsed on the GPU into the batch format (include/bioalign.h).
+    `text` is bytes / a uint8 array on the host, or a raw device address (int) with length `length`."""
+
+    def __init__(self, engine: Engine, text, length: int | None = None, device_index: int = 0):
+        self.engine = engine
+        if isinstance(text, int):
+            ptr, n, on_dev = text, int(length), 1
+            self._keep = None
+        else:
+            arr = np.frombuffer(bytes(text), dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, dtype=np.uint8)
+            self._keep = arr
+            ptr, n, on_dev = (arr.ctypes.data if arr.size else None), int(arr.size), 0
+        h = lib().bioalign_fasta_parse(engine._h, device_index, ptr, n, on_dev)
+        if not h:
+            engine._raise(EINVAL)
+        self._h = C.c_void_p(h)
+        L = lib()
+        self.count = int(L.bioalign_fasta_count(self._h))
+        self.total_bytes = int(L.bioalign_fasta_bytes(self._h))
+        self.kernel_ms = float(L.bioalign_fasta_kernel_ms(self._h))
+        self.d_seq = int(L.bioalign_fasta_device_seq(self._h) or 0)
+        self.d_off = int(L.bioalign_fasta_device_off(self._h) or 0)
+
+        def host(fn, k):
+            p = fn(self._h)
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(k,)).copy() if k else np.zeros(0, np.uint64)
+
+        self.off = host(L.bioalign_fasta_off, self.count + 1)
+        self.header_begin = host(L.bioalign_fasta_header_begin, self.count)
+        self.header_len = host(L.bioalign_fasta_header_len, self.count)
+
+    def seq_bytes(self) -> np.ndarray:
+        out = np.zeros(max(self.total_bytes, 1), dtype=np.uint8)
+        rc = lib().bioalign_fasta_copy_seq(self._h, out.ctypes.data)
+        if rc != 0:
+            self.engine._raise(rc)
+        return out[:self.total_bytes]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().bioalign_fasta_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

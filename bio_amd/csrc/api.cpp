@@ -1351,3 +1351,182 @@ extern "C" int bioalign_stripe_walk(bioalign_stripe *x, uint64_t i, uint64_t j_l
     if (!t1 || !t2 || !len || !exit_i || !exit_j) return x->ctx->fail(BIOALIGN_EINVAL, "null argument");
     return stripe_walk(*x, i, j_local, t1, t2, len, exit_i, exit_j);
 }
+
+// ----------------------------------------------------------------------------
+// FASTA text -> the batch format in HBM (ReadFASTA, fasta.go:55-84; kernels_fasta.hip)
+// ----------------------------------------------------------------------------
+extern "C" hipError_t ba_launch_fasta_count(const BaFastaParams &P, hipStream_t st);
+extern "C" hipError_t ba_launch_fasta_scan1(uint64_t *a, uint64_t *b, uint64_t n, uint64_t *tot, hipStream_t st);
+extern "C" hipError_t ba_launch_fasta_starts(const BaFastaParams &P, hipStream_t st);
+extern "C" hipError_t ba_launch_fasta_lines_a(const BaFastaParams &P, hipStream_t st);
+extern "C" hipError_t ba_launch_fasta_lines_b(const BaFastaParams &P, hipStream_t st);
+
+struct bioalign_fasta {
+    bioalign_ctx *ctx = nullptr;
+    int dev = 0;
+    uint64_t n_records = 0, total = 0, n_lines = 0;
+    DevBuf seq, off;  // device: the records' data back to back, [n_records + 1] offsets
+    std::vector<uint64_t> h_off, h_hdr_begin, h_hdr_len;
+    float kernel_ms = 0.f;
+};
+
+namespace {
+
+#define FA_TRY(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            ctx->fail(BIOALIGN_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return BIOALIGN_EHIP;                                                                      \
+        }                                                                                              \
+    } while (0)
+
+int fasta_parse(bioalign_fasta &F, const uint8_t *text, uint64_t len, bool on_device)
+{
+    bioalign_ctx *ctx = F.ctx;
+    const uint64_t CHUNK = 16384, LPB = 2048;
+    FA_TRY(hipSetDevice(ctx->devices[F.dev]));
+    const uint64_t n_chunks = std::max<uint64_t>((len + CHUNK - 1) / CHUNK, 1);
+    if (n_chunks > 0x7fffffffull) return ctx->fail(BIOALIGN_EUNSUPPORTED, "FASTA text of %llu bytes is too long for one call", (unsigned long long)len);
+    DevBuf d_text, d_cnt;
+    int rc;
+    if ((rc = d_cnt.alloc(ctx, n_chunks * 8 + 16))) return rc;
+    uint64_t *const d_tot = d_cnt.as<uint64_t>() + n_chunks;
+    hipStream_t st = nullptr;
+    const uint8_t *dtext = text;  // text already in HBM: parsed where it lies
+    if (!on_device) {
+        if ((rc = d_text.alloc(ctx, len + 16))) return rc;
+        if (len) FA_TRY(hipMemcpyAsync(d_text.p, text, len, hipMemcpyHostToDevice, st));
+        dtext = d_text.as<uint8_t>();
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    FA_TRY(hipEventCreate(&e0));
+    FA_TRY(hipEventCreate(&e1));
+    struct Ev {
+        hipEvent_t &a, &b;
+        ~Ev()
+        {
+            (void)hipEventDestroy(a);
+            (void)hipEventDestroy(b);
+        }
+    } ev{e0, e1};
+    FA_TRY(hipEventRecord(e0, st));
+
+    BaFastaParams P{};
+    P.text = dtext;
+    P.len = len;
+    P.n_chunks = n_chunks;
+    P.chunk_count = d_cnt.as<uint64_t>();
+    FA_TRY(ba_launch_fasta_count(P, st));
+    FA_TRY(ba_launch_fasta_scan1(P.chunk_count, nullptr, n_chunks, d_tot, st));
+    uint64_t tot[2] = {0, 0};
+    FA_TRY(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, st));
+    FA_TRY(hipStreamSynchronize(st));
+    const uint64_t n_lines = tot[0] + 1;  // bytes.Split: one piece more than separators (fasta.go:62)
+    const uint64_t n_lb = (n_lines + LPB - 1) / LPB;
+    F.n_lines = n_lines;
+
+    // the per-line arrays in one allocation
+    auto up = [](uint64_t v) { return (v + 255) & ~255ull; };
+    const uint64_t o_ls = 0, o_tb = o_ls + up(n_lines * 8), o_ld = o_tb + up(n_lines * 8), o_lh = o_ld + up(n_lines * 8),
+                   o_pd = o_lh + up(n_lines * 8), o_ph = o_pd + up(n_lb * 8), o_tl = o_ph + up(n_lb * 8),
+                   ws_bytes = o_tl + up(n_lines * 4);
+    DevBuf d_ws;
+    if ((rc = d_ws.alloc(ctx, ws_bytes))) return rc;
+    uint8_t *const ws = d_ws.as<uint8_t>();
+    P.line_start = reinterpret_cast<uint64_t *>(ws + o_ls);
+    P.n_lines = n_lines;
+    P.n_line_blocks = n_lb;
+    P.trim_begin = reinterpret_cast<uint64_t *>(ws + o_tb);
+    P.trim_len = reinterpret_cast<uint32_t *>(ws + o_tl);
+    P.ldata = reinterpret_cast<uint64_t *>(ws + o_ld);
+    P.lhdr = reinterpret_cast<uint64_t *>(ws + o_lh);
+    P.part_data = reinterpret_cast<uint64_t *>(ws + o_pd);
+    P.part_hdr = reinterpret_cast<uint64_t *>(ws + o_ph);
+    FA_TRY(hipMemsetAsync(P.line_start, 0, 8, st));  // line 0 starts at 0
+    FA_TRY(ba_launch_fasta_starts(P, st));
+    FA_TRY(ba_launch_fasta_lines_a(P, st));
+    FA_TRY(ba_launch_fasta_scan1(P.part_data, P.part_hdr, n_lb, d_tot, st));
+    FA_TRY(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, st));
+    FA_TRY(hipStreamSynchronize(st));
+    F.total = tot[0];
+    F.n_records = tot[1];
+
+    DevBuf d_tmp;  // header spans + the error word
+    if ((rc = F.seq.alloc(ctx, F.total + 16)) || (rc = F.off.alloc(ctx, (F.n_records + 1) * 8)) ||
+        (rc = d_tmp.alloc(ctx, F.n_records * 16 + 16)))
+        return rc;
+    uint64_t *const d_hb = d_tmp.as<uint64_t>(), *const d_hl = d_hb + F.n_records;
+    uint32_t *const d_err = reinterpret_cast<uint32_t *>(d_hl + F.n_records);
+    P.seq = F.seq.as<uint8_t>();
+    P.off = F.off.as<uint64_t>();
+    P.hdr_begin = d_hb;
+    P.hdr_len = d_hl;
+    P.error = d_err;
+    FA_TRY(hipMemsetAsync(d_err, 0, 4, st));
+    FA_TRY(ba_launch_fasta_lines_b(P, st));
+    FA_TRY(hipMemcpyAsync(F.off.as<uint64_t>() + F.n_records, &F.total, 8, hipMemcpyHostToDevice, st));
+    FA_TRY(hipEventRecord(e1, st));
+    uint32_t err = 0;
+    F.h_off.assign(F.n_records + 1, 0);
+    F.h_hdr_begin.assign(F.n_records, 0);
+    F.h_hdr_len.assign(F.n_records, 0);
+    FA_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st));
+    FA_TRY(hipMemcpyAsync(F.h_off.data(), F.off.p, (F.n_records + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (F.n_records) {
+        FA_TRY(hipMemcpyAsync(F.h_hdr_begin.data(), d_hb, F.n_records * 8, hipMemcpyDeviceToHost, st));
+        FA_TRY(hipMemcpyAsync(F.h_hdr_len.data(), d_hl, F.n_records * 8, hipMemcpyDeviceToHost, st));
+    }
+    FA_TRY(hipStreamSynchronize(st));
+    (void)hipEventElapsedTime(&F.kernel_ms, e0, e1);
+    if (err) return ctx->fail(BIOALIGN_EINVAL, "No header");  // the reference's error text (fasta.go:73)
+    return 0;
+}
+
+}  // namespace
+
+extern "C" bioalign_fasta *bioalign_fasta_parse(bioalign_ctx *ctx, int device_index, const uint8_t *text, uint64_t len,
+                                                int text_on_device)
+{
+    if (!ctx) return nullptr;
+    if (device_index < 0 || device_index >= (int)ctx->devices.size()) {
+        ctx->fail(BIOALIGN_EINVAL, "device index %d out of range", device_index);
+        return nullptr;
+    }
+    if (!text && len) {
+        ctx->fail(BIOALIGN_EINVAL, "null text");
+        return nullptr;
+    }
+    bioalign_fasta *F = new bioalign_fasta;
+    F->ctx = ctx;
+    F->dev = device_index;
+    if (fasta_parse(*F, text, len, text_on_device != 0) != 0) {
+        delete F;
+        return nullptr;
+    }
+    return F;
+}
+
+extern "C" void bioalign_fasta_destroy(bioalign_fasta *F)
+{
+    if (!F) return;
+    (void)hipSetDevice(F->ctx->devices[F->dev]);
+    delete F;
+}
+extern "C" uint64_t bioalign_fasta_count(const bioalign_fasta *F) { return F ? F->n_records : 0; }
+extern "C" uint64_t bioalign_fasta_bytes(const bioalign_fasta *F) { return F ? F->total : 0; }
+extern "C" float bioalign_fasta_kernel_ms(const bioalign_fasta *F) { return F ? F->kernel_ms : 0.f; }
+extern "C" const uint8_t *bioalign_fasta_device_seq(const bioalign_fasta *F) { return F ? F->seq.as<uint8_t>() : nullptr; }
+extern "C" const uint64_t *bioalign_fasta_device_off(const bioalign_fasta *F) { return F ? F->off.as<uint64_t>() : nullptr; }
+extern "C" const uint64_t *bioalign_fasta_off(const bioalign_fasta *F) { return F ? F->h_off.data() : nullptr; }
+extern "C" const uint64_t *bioalign_fasta_header_begin(const bioalign_fasta *F) { return F ? F->h_hdr_begin.data() : nullptr; }
+extern "C" const uint64_t *bioalign_fasta_header_len(const bioalign_fasta *F) { return F ? F->h_hdr_len.data() : nullptr; }
+extern "C" int bioalign_fasta_copy_seq(const bioalign_fasta *F, uint8_t *dst)
+{
+    if (!F) return BIOALIGN_EINVAL;
+    bioalign_ctx *ctx = F->ctx;
+    if (!dst && F->total) return ctx->fail(BIOALIGN_EINVAL, "null destination");
+    HIP_TRY(ctx, hipSetDevice(ctx->devices[F->dev]));
+    if (F->total) HIP_TRY(ctx, hipMemcpy(dst, F->seq.p, F->total, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -131,3 +131,20 @@ struct BaLongParams {
     int scan_only;                 // walk: find the end cell of this stripe's bottom row, report it, stop
 };
 
+// FASTA text -> concatenated sequences + offsets (kernels_fasta.hip)
+struct BaFastaParams {
+    const uint8_t *text;      // device, len bytes
+    uint64_t len;
+    uint64_t n_chunks;
+    uint64_t *chunk_count;    // [n_chunks] newlines per chunk, then (scanned) newlines before the chunk
+    uint64_t *line_start;     // [n_lines]
+    uint64_t n_lines, n_line_blocks;
+    uint64_t *trim_begin;     // [n_lines] first byte of the trimmed line
+    uint32_t *trim_len;       // [n_lines] its length (0: blank)
+    uint64_t *ldata, *lhdr;   // [n_lines] sequence bytes / header flag of the line, then (scanned) the totals before it
+    uint64_t *part_data, *part_hdr;  // [n_line_blocks] block sums, then scanned
+    uint8_t *seq;             // out: the records' data back to back
+    uint64_t *off;            // out: [n_records + 1]
+    uint64_t *hdr_begin, *hdr_len;   // out: [n_records] header lines as spans of the text
+    uint32_t *error;          // out: != 0: data before the first header
+};

@@ -1,0 +1,75 @@
+"""Host mirror of the reference's FASTA reader (fasta.go) over the GPU parser (bioalign_fasta_parse).
+
+ReadFASTA keeps the reference's contract (fasta.go:47-84): one FASTASeq per header line, headers stored
+unparsed, blank lines and surrounding white space dropped, lf and crlf alike, ValueError("No header") where
+the reference returns that error.  FastaBatch is the additive, device-resident form: the sequences stay in HBM
+as concatenated bytes + offsets, the shape bioalign_plan_run takes, so reads go from file bytes to alignment
+without a host pass over them.  There is no CPU parser here: without the GPU library these calls fail.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+from . import _native
+from ._native import BioAlignError
+
+
+@dataclass
+class FASTASeq:
+    """fasta.go:17-20"""
+    Header: str
+    Seq: bytes
+
+    def ID(self) -> str:  # fasta.go:23-33
+        if self.Header == "":
+            return ""
+        ident = self.Header[1:]
+        sp = ident.find(" ")
+        return ident[:sp] if sp >= 0 else ident
+
+    def Desc(self) -> str:  # fasta.go:36-45
+        if self.Header == "":
+            return ""
+        ident = self.Header[1:]
+        sp = ident.find(" ")
+        return ident[sp + 1:] if sp >= 0 else ""
+
+
+class FastaBatch:
+    """The parsed records, resident on the device: .count, .off (host offsets), .d_seq / .d_off (device
+    addresses), .headers (host strings), .kernel_ms."""
+
+    def __init__(self, text, engine=None):
+        from .align import engine as default_engine
+
+        self.text = bytes(text)
+        self._fa = _native.Fasta(engine or default_engine(), self.text)
+        self.count, self.off = self._fa.count, self._fa.off
+        self.d_seq, self.d_off, self.kernel_ms = self._fa.d_seq, self._fa.d_off, self._fa.kernel_ms
+        self.headers = [self.text[int(b):int(b + l)].decode("latin-1")
+                        for b, l in zip(self._fa.header_begin, self._fa.header_len)]
+
+    def sequences(self):
+        raw = self._fa.seq_bytes().tobytes()
+        return [raw[int(self.off[k]):int(self.off[k + 1])] for k in range(self.count)]
+
+
+def ReadFASTA(data) -> list:
+    """fasta.go:55-84.  `data`: bytes, or a file-like object with .read()."""
+    if hasattr(data, "read"):
+        data = data.read()
+    if isinstance(data, str):
+        data = data.encode()
+    try:
+        fb = FastaBatch(data)
+    except BioAlignError as e:
+        if "No header" in str(e):
+            raise ValueError("No header") from None  # errors.New("No header"), fasta.go:73
+        raise
+    return [FASTASeq(h, s) for h, s in zip(fb.headers, fb.sequences())]
+
+
+def ReadFASTAFile(path: str) -> list:
+    """fasta.go:88-95"""
+    with open(path, "rb") as f:
+        return ReadFASTA(f)

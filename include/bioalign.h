@@ -211,6 +211,31 @@ int bioalign_stripe_walk(bioalign_stripe *stripe, uint64_t i, uint64_t j_local, 
                          uint64_t *len, uint64_t *exit_i, uint64_t *exit_j);
 
 /*
+ * FASTA text -> the batch format, on the GPU (the step before the DP path; ReadFASTA, fasta.go:55-84).
+ * The text (host memory, or device memory with text_on_device != 0) is split at '\n', every line trimmed of
+ * ASCII white space at both ends, blank lines skipped, a line starting with '>' opens a record, other lines
+ * are appended to the last record; data before the first header fails with the reference's "No header".
+ * What comes back stays in HBM in the shape bioalign_plan_run takes: device_seq = the records' data back to
+ * back, device_off = count + 1 uint64 offsets.  off (host copy of the offsets, what bioalign_plan_create
+ * needs) and header_begin / header_len (every header line, trimmed, as a span of the caller's text: FASTASeq's
+ * Header, fasta.go:17-20) are host arrays owned by the object.  (Go's TrimSpace also trims UTF-8 encoded
+ * Unicode spaces; bytes >= 0x80 are never trimmed here.)
+ */
+typedef struct bioalign_fasta bioalign_fasta;
+bioalign_fasta *bioalign_fasta_parse(bioalign_ctx *ctx, int device_index, const uint8_t *text, uint64_t len,
+                                     int text_on_device);
+void bioalign_fasta_destroy(bioalign_fasta *fasta);
+uint64_t bioalign_fasta_count(const bioalign_fasta *fasta);           /* records */
+uint64_t bioalign_fasta_bytes(const bioalign_fasta *fasta);           /* sequence bytes of all records */
+float bioalign_fasta_kernel_ms(const bioalign_fasta *fasta);          /* the parse on the device, milliseconds */
+const uint8_t *bioalign_fasta_device_seq(const bioalign_fasta *fasta);
+const uint64_t *bioalign_fasta_device_off(const bioalign_fasta *fasta);
+const uint64_t *bioalign_fasta_off(const bioalign_fasta *fasta);
+const uint64_t *bioalign_fasta_header_begin(const bioalign_fasta *fasta);
+const uint64_t *bioalign_fasta_header_len(const bioalign_fasta *fasta);
+int bioalign_fasta_copy_seq(const bioalign_fasta *fasta, uint8_t *dst); /* all sequence bytes to host memory */
+
+/*
  * Timing hooks for the benchmark (no counterpart in the reference): the plan
  * records a pair of HIP events around every DP kernel launch, on the launch
  * stream, into a fixed pool of 256 pairs.  Once the stream has been

@@ -962,3 +962,39 @@ int64_t bo_batch(int kind, int mode, const uint8_t *s1, const uint64_t *s1_off,
     free(jobs);
     return rc ? rc : cells;
 }
+
+/* ---------------------------------------------------------------------------
+ * ReadFASTA, fasta.go:55-84
+ * ------------------------------------------------------------------------- */
+static int bo_is_space(uint8_t c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+
+int64_t bo_read_fasta(const uint8_t *text, uint64_t len, uint8_t *seq, uint64_t *off, uint64_t *hdr_begin,
+                      uint64_t *hdr_len)
+{
+    int64_t nrec = 0;
+    uint64_t out = 0, pos = 0;
+    int found_header = 0;
+    while (pos <= len) {                       /* bytes.Split yields a last, possibly empty, piece (fasta.go:62) */
+        uint64_t e = pos;
+        while (e < len && text[e] != '\n') ++e;
+        uint64_t b = pos, t = e;               /* bytes.TrimSpace (fasta.go:63) */
+        while (b < t && bo_is_space(text[b])) ++b;
+        while (t > b && bo_is_space(text[t - 1])) --t;
+        if (t > b) {                           /* blank lines are skipped (fasta.go:65-66) */
+            if (text[b] == '>') {              /* new record (fasta.go:67-71) */
+                found_header = 1;
+                hdr_begin[nrec] = b;
+                hdr_len[nrec] = t - b;
+                off[nrec] = out;
+                ++nrec;
+            } else {
+                if (!found_header) return -1;  /* "No header" (fasta.go:72-73) */
+                memcpy(seq + out, text + b, t - b);  /* fasta.go:75 */
+                out += t - b;
+            }
+        }
+        pos = e + 1;
+    }
+    off[nrec] = out;
+    return nrec;
+}

@@ -133,6 +133,18 @@ int64_t bo_batch(int kind, int mode, const uint8_t *s1, const uint64_t *s1_off,
                  bo_aligner *a, int64_t gap_open, int64_t gap_extend, int threads,
                  int64_t *scores, uint8_t *t1, uint8_t *t2, uint64_t *tlen);
 
+/*
+ * ReadFASTA (fasta.go:55-84): the text is split at '\n', every line trimmed of white space at both ends
+ * (bytes.TrimSpace; restated for ASCII white space: \t \n \v \f \r and space -- Go would also trim UTF-8
+ * encoded Unicode spaces, which FASTA files do not hold), blank lines skipped, a line that starts with '>'
+ * opens a new record (even if no data follows), other lines are appended to the last record.
+ * Data before the first header is the error "No header": returns -1.
+ * Outputs: seq = the records' data back to back (capacity: len), off[0..n] (capacity: lines + 2),
+ * hdr_begin / hdr_len = every header line, trimmed, as a span of the text.  Returns the number of records.
+ */
+int64_t bo_read_fasta(const uint8_t *text, uint64_t len, uint8_t *seq, uint64_t *off, uint64_t *hdr_begin,
+                      uint64_t *hdr_len);
+
 #ifdef __cplusplus
 }
 #endif

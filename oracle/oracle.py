@@ -78,6 +78,8 @@ def lib():
         L.bo_batch.argtypes = [C.c_int, C.c_int, u8p, C.POINTER(C.c_uint64), u8p, C.POINTER(C.c_uint64),
                                C.c_uint64, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                i64p, u8p, u8p, C.POINTER(C.c_uint64)]
+        L.bo_read_fasta.restype = C.c_int64
+        L.bo_read_fasta.argtypes = [u8p, C.c_uint64, u8p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -261,3 +263,20 @@ def batch(kind: int, mode: str, s1: np.ndarray, s1_off: np.ndarray, s2: np.ndarr
         _check(int(rc))
         raise RuntimeError(f"oracle batch failed: {rc}")
     return scores, t1, t2, tlen, int(rc)
+
+
+def ReadFASTA(text: bytes):
+    """fasta.go:55-84 -> list of (header, seq) byte strings; raises ValueError("No header") as the reference errors."""
+    text = bytes(text)
+    n = len(text)
+    lines = text.count(b"\n") + 2
+    buf = _buf(text)
+    seq = (C.c_uint8 * max(n, 1))()
+    off = (C.c_uint64 * (lines + 1))()
+    hb = (C.c_uint64 * (lines + 1))()
+    hl = (C.c_uint64 * (lines + 1))()
+    k = lib().bo_read_fasta(buf, n, seq, off, hb, hl)
+    if k < 0:
+        raise ValueError("No header")
+    raw = bytes(seq)
+    return [(text[hb[i]:hb[i] + hl[i]], raw[off[i]:off[i + 1]]) for i in range(k)]

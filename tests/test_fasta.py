@@ -1,0 +1,104 @@
+"""FASTA ingestion: ReadFASTA, fasta.go:55-84.
+
+CPU: the oracle's restatement against the reference's own example (fasta_test.go:10-44: the only golden vector the
+reference holds for this path) and the documented behaviours of fasta.go:47-54.  GPU: the parser kernels
+(kernels_fasta.hip, through bioalign_fasta_parse) byte for byte against the oracle on texts built around every
+rule -- crlf, blank lines, white space at both ends and inside lines, records without data, no trailing newline,
+lines across the 16 KB chunks and the 64-byte thread spans, the "No header" error -- and the device-resident
+result fed straight into the aligner."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+EXAMPLE = b">db|123|abc example sequence\nAGACCA\nTACCA"   # fasta_test.go:11-13
+
+
+def test_oracle_matches_the_reference_example():
+    recs = O.ReadFASTA(EXAMPLE)
+    assert recs == [(b">db|123|abc example sequence", b"AGACCATACCA")]  # fasta_test.go:23-26
+
+
+def test_oracle_documented_behaviour():
+    # fasta.go:47-54: blank lines allowed, white space trimmed, lf and crlf, a record for every header
+    assert O.ReadFASTA(b"\n  >a x \r\nAC GT \r\n\r\n>b\n>c\n  TT\n") == [(b">a x", b"AC GT"), (b">b", b""), (b">c", b"TT")]
+    assert O.ReadFASTA(b"") == [] and O.ReadFASTA(b"\n\n \n") == []
+    with pytest.raises(ValueError, match="No header"):
+        O.ReadFASTA(b"ACGT\n>a\nAC\n")
+
+
+def test_id_and_desc_host_side():
+    from bio_amd.fasta import FASTASeq
+    f = FASTASeq(">db|123|abc example sequence", b"")
+    assert (f.ID(), f.Desc()) == ("db|123|abc", "example sequence")   # fasta_test.go:41-43
+    assert (FASTASeq(">x", b"").ID(), FASTASeq(">x", b"").Desc(), FASTASeq("", b"").ID()) == ("x", "", "")
+
+
+def _texts():
+    rng = random.Random(12)
+    alpha = b"ACGT"
+    out = [EXAMPLE, b"", b"\n", b">only", b">a\n", b">a\r\nAC\r\nGT\r\n", b" \t>a  \n\t AC GT\t\n\n\n>b\n\n>c\nT",
+           b">a\n" + b"A" * 70000 + b"\n", b">a\n" + b"\n" * 40000 + b"C\n", b">h\n" + b" " * 20000 + b"G" + b" " * 20000]
+    for k in range(6):  # many records, line lengths around the 64-byte spans, text across several 16 KB chunks
+        parts = []
+        for r in range(rng.randrange(1, 400)):
+            parts.append(b">rec%d some words %d" % (r, k) + rng.choice([b"\n", b"\r\n", b" \n"]))
+            for _ in range(rng.randrange(0, 6)):
+                ln = rng.choice([0, 1, 59, 60, 61, 63, 64, 65, 127, 128, 150, 250, rng.randrange(0, 700)])
+                parts.append(rng.choice([b"", b" ", b"\t"]) + bytes(rng.choice(alpha) for _ in range(ln)) +
+                             rng.choice([b"\n", b"\r\n", b"  \n", b"\n\n"]))
+        text = b"".join(parts)
+        out.append(text if k % 2 else text.rstrip(b"\r\n"))
+    return out
+
+
+@pytest.mark.gpu
+def test_gpu_parser_equals_oracle():
+    import bio_amd
+    for text in _texts():
+        want = O.ReadFASTA(text)
+        got = bio_amd.ReadFASTA(text)
+        assert [(f.Header.encode("latin-1"), f.Seq) for f in got] == want, len(text)
+    with pytest.raises(ValueError, match="No header"):
+        bio_amd.ReadFASTA(b"  \nACGT\n>a\nAC\n")
+    with pytest.raises(ValueError, match="No header"):
+        bio_amd.ReadFASTA(b">late" * 0 + b"A" * 40000 + b"\n>a\n")
+
+
+@pytest.mark.gpu
+def test_fasta_to_alignment_without_a_host_copy():
+    # reads and references from two FASTA texts, parsed on the GPU, aligned from where the parser left them
+    import torch
+    import bio_amd
+    from bio_amd import _native, synth
+
+    s1, o1, s2, o2 = synth.dna_pairs(300, 90, 100, config=2)
+    def fasta(s, o, tag):
+        rows = []
+        for p in range(len(o) - 1):
+            seq = s[int(o[p]):int(o[p + 1])].tobytes()
+            rows.append(b">%s%d\r\n" % (tag, p) + seq[:60] + b"\n" + seq[60:] + b"\n\n")
+        return b"".join(rows)
+    fa, fb = bio_amd.FastaBatch(fasta(s1, o1, b"read")), bio_amd.FastaBatch(fasta(s2, o2, b"ref"))
+    assert fa.count == fb.count == 300 and np.array_equal(fa.off, o1) and np.array_equal(fb.off, o2)
+    table, c1, c2 = synth.dna_table(1, -1)
+    eng = bio_amd.align.engine()
+    # lengths only on the host side (the plan needs them); the bytes never come back
+    pb = _native.PackedBatch(np.zeros(1, np.uint8), fa.off, np.zeros(1, np.uint8), fb.off, "fitting", table, c1, c2, 1, 1)
+    plan = eng.plan(pb)
+    dev = torch.device("cuda:0")
+    N, cap = 300, int(fa.off[-1] + fb.off[-1])
+    sc = torch.empty(N, dtype=torch.int64, device=dev)
+    t1 = torch.zeros(cap + 16, dtype=torch.uint8, device=dev); t2 = torch.zeros(cap + 16, dtype=torch.uint8, device=dev)
+    toff = torch.empty(N, dtype=torch.int64, device=dev); tlen = torch.empty(N, dtype=torch.int64, device=dev)
+    plan.run(fa.d_seq, fa.d_off, fb.d_seq, fb.d_off, sc.data_ptr(), t1.data_ptr(), t2.data_ptr(), toff.data_ptr(),
+             tlen.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    sc, t1, t2, toff, tlen = (x.cpu().numpy() for x in (sc, t1, t2, toff, tlen))
+    oa = O.MatchAligner(1, -1)
+    for p in range(0, N, 7):
+        x, y = s1[int(o1[p]):int(o1[p + 1])].tobytes(), s2[int(o2[p]):int(o2[p + 1])].tobytes()
+        a, l = int(toff[p]), int(tlen[p])
+        assert (int(sc[p]), t1[a:a + l].tobytes(), t2[a:a + l].tobytes()) == O.AlignPair("fitting", x, y, oa, 1)
