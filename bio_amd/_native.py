@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("BIOALIGN_LIB") or os.path.join(_HERE, "lib", "libbioa
 GLOBAL, LOCAL, FITTING, OVERLAP = 0, 1, 2, 3
 MODES = {"global": GLOBAL, "local": LOCAL, "fitting": FITTING, "overlap": OVERLAP}
 SCORE_ONLY = 1
+DENSE_TRACES = 2  # plans: traces back to back in pair order instead of in per-pair slots
 EINVAL, ENODEVICE, ENOMEM, EHIP, EUNSUPPORTED = -1, -2, -3, -4, -5
 
 # every symbol include/bioalign.h declares
@@ -249,16 +250,22 @@ class Engine:
         """bioalign_long on host buffers -> (scores, t1, t2, t_off, t_len); self.last_kernel_ms is set."""
         return self.batch(pb, long=True)
 
-    def batch(self, pb: PackedBatch, long: bool = False):
-        """bioalign_batch on host buffers -> (scores, t1, t2, t_off, t_len)."""
+    def batch(self, pb: PackedBatch, long: bool = False, out=None):
+        """bioalign_batch on host buffers -> (scores, t1, t2, t_off, t_len).  `out`: the tuple a previous call on a
+        batch of the same size returned, to write into the same buffers again."""
         n = pb.n_pairs
-        scores = np.zeros(max(n, 1), dtype=np.int64)
         score_only = bool(pb.c.flags & SCORE_ONLY)
         cap = pb.trace_capacity
-        t1 = np.zeros(cap + 1, dtype=np.uint8)
-        t2 = np.zeros(cap + 1, dtype=np.uint8)
-        t_off = np.zeros(max(n, 1), dtype=np.uint64)
-        t_len = np.zeros(max(n, 1), dtype=np.uint64)
+        if out is not None:
+            scores, t1, t2, t_off, t_len = out
+            if len(scores) < n or len(t1) < cap or len(t2) < cap or len(t_off) < n or len(t_len) < n:
+                raise ValueError("output buffers too small for this batch")
+        else:
+            scores = np.zeros(max(n, 1), dtype=np.int64)
+            t1 = np.zeros(cap + 1, dtype=np.uint8)
+            t2 = np.zeros(cap + 1, dtype=np.uint8)
+            t_off = np.zeros(max(n, 1), dtype=np.uint64)
+            t_len = np.zeros(max(n, 1), dtype=np.uint64)
         r = Result()
         r.scores = scores.ctypes.data
         if not score_only:

@@ -23,7 +23,11 @@
 extern "C" size_t ba_dp_linear_lds_bytes(int nb, int nb4, int na_pad, int R, int waves);
 extern "C" hipError_t ba_launch_pack(const BaPackParams &P, hipStream_t st);
 extern "C" hipError_t ba_launch_dp_linear(const BaDpParams &P, int mode, int R, int K, int waves, hipStream_t st);
-extern "C" hipError_t ba_launch_trace_linear(const BaTraceParams &P, int mode, int R, int K, hipStream_t st);
+extern "C" hipError_t ba_launch_trace_linear(const BaTraceParams &P, int mode, int R, int K, int phases, hipStream_t st);
+extern "C" hipError_t ba_launch_len_partial(const uint64_t *len, uint64_t n, uint64_t *part, hipStream_t st);
+extern "C" hipError_t ba_launch_len_apply(const uint64_t *len, uint64_t n, const uint64_t *part, uint64_t *t_off,
+                                          uint64_t *dense_end, hipStream_t st);
+extern "C" hipError_t ba_launch_fasta_scan1(uint64_t *a, uint64_t *b, uint64_t n, uint64_t *tot, hipStream_t st);
 extern "C" size_t ba_dp_affine_lds_bytes(int nb, int nb4, int na_pad, int R, int waves, int nib);
 extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, int waves, int pipe, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_affine(const BaTraceParams &P, int mode, int R, hipStream_t st);
@@ -97,6 +101,9 @@ struct bioalign_plan {
     int32_t *d_hb = nullptr;
     uint32_t *d_dir = nullptr;
     void *d_rec = nullptr;  // move records of the linear-gap walk (16 bytes per 16 trace columns)
+    // dense trace layout (bioalign_batch: what goes back over PCIe is the traces, not their slots)
+    bool want_dense = false, dense = false;
+    uint64_t *d_dense_end = nullptr, *d_len_part = nullptr;
     BaLocalBest *d_best = nullptr;
     uint64_t ws_bytes = 0;
     // timing hooks: a fixed pool of event pairs, one pair per DP launch since the last reset
@@ -211,6 +218,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     pl->mode = in->mode;
     pl->affine = in->gap_open != in->gap_extend;
     pl->score_only = (in->flags & BIOALIGN_SCORE_ONLY) != 0;
+    pl->want_dense = (in->flags & BIOALIGN_DENSE_TRACES) != 0;
     pl->gap = pl->gap_open = in->gap_open;
     pl->gap_ext = in->gap_extend;
     pl->gap_symbol = in->gap_symbol;
@@ -411,6 +419,13 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     if ((rc = dev_alloc(pl, (void **)&pl->d_hb, m_hb * 4))) return rc;
     if ((rc = dev_alloc(pl, (void **)&pl->d_dir, m_dir * 4))) return rc;
     if (use_rec && (rc = dev_alloc(pl, &pl->d_rec, m_rec * 16))) return rc;
+    // dense layout: the walks of the whole batch come first, then one scan of the lengths, then the expansion --
+    // which needs every pair's move records at once: one chunk, linear gaps
+    pl->dense = pl->want_dense && use_rec && pl->chunks.size() == 1;
+    if (pl->dense) {
+        if ((rc = dev_alloc(pl, (void **)&pl->d_dense_end, N * 8))) return rc;
+        if ((rc = dev_alloc(pl, (void **)&pl->d_len_part, ((N + 2047) / 2048 + 2) * 8))) return rc;
+    }
     if ((rc = dev_alloc(pl, (void **)&pl->d_best, (N ? N : 1) * sizeof(BaLocalBest)))) return rc;
     if (pl->affine) {
         // Run the strips of a bundle as a pipeline over the waves of a block (as many waves as strips, up to
@@ -460,6 +475,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         // step gets slower (10.5 -> 11.4 ms with 4 slices, 13.4 ms with 8); BIOALIGN_SLICES=n turns it on.
         const uint64_t want = env_u64("BIOALIGN_SLICES", 1);
         pl->slices = (!pl->score_only && biggest >= 4096 && want > 1) ? (int)std::min<uint64_t>(want, 16) : 1;
+        if (pl->dense) pl->slices = 1;  // (the scan of the lengths sits between the walks and the expansion of the whole batch)
         if (pl->slices > 1) {
             HIP_TRY(ctx, hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
             pl->ev_slice.resize(pl->slices);
@@ -607,10 +623,21 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             tr.t_off = d_t_off;
             tr.t_len = d_t_len;
             tr.rec = pl->d_rec;
-            if (pl->affine)
+            tr.dense_end = nullptr;
+            if (pl->affine) {
                 HIP_TRY(ctx, ba_launch_trace_affine(tr, pl->mode, pl->R, ts));
-            else
-                HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, ts));
+            } else if (!pl->dense) {
+                HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 3, ts));
+            } else {
+                // walk -> prefix sums of the lengths in pair order -> expansion to the dense places
+                HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 1, ts));
+                const uint64_t nparts = (pl->n_pairs + 2047) / 2048;
+                HIP_TRY(ctx, ba_launch_len_partial(d_t_len, pl->n_pairs, pl->d_len_part, ts));
+                HIP_TRY(ctx, ba_launch_fasta_scan1(pl->d_len_part, nullptr, nparts, pl->d_len_part + nparts, ts));
+                HIP_TRY(ctx, ba_launch_len_apply(d_t_len, pl->n_pairs, pl->d_len_part, d_t_off, pl->d_dense_end, ts));
+                tr.dense_end = pl->d_dense_end;
+                HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 2, ts));
+            }
         }
         if (slices > 1) {
             // the caller's stream owns the results (and the workspace, for the next chunk or run) again
@@ -686,14 +713,25 @@ static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *i
         o1[p] = in->s1_off[lo + p] - b1;
         o2[p] = in->s2_off[lo + p] - b2;
     }
+    // BIOALIGN_TIMING=1: where the wall time of a share goes, one line on stderr
+    const bool timing = env_u64("BIOALIGN_TIMING", 0) != 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(now() - t).count();
+    };
+    const auto t_start = now();
+    double t_plan = 0, t_alloc = 0, t_h2d = 0, t_kern = 0, t_d2h = 0;
     bioalign_batch_t sub = *in;
     sub.s1 = in->s1 ? in->s1 + b1 : nullptr;
     sub.s2 = in->s2 ? in->s2 + b2 : nullptr;
     sub.s1_off = o1.data();
     sub.s2_off = o2.data();
     sub.n_pairs = N;
+    sub.flags |= BIOALIGN_DENSE_TRACES;  // where the plan can: only the traces themselves go back over PCIe
     bioalign_plan *pl = bioalign_plan_create(&local, dev_index, &sub);
     if (!pl) return fail(local.code ? local.code : BIOALIGN_EINVAL);
+    t_plan = ms_since(t_start);
+    auto t_mark = now();
     const bool traces = !pl->score_only;
     const uint64_t bytes1 = o1[N], bytes2 = o2[N], cap = bytes1 + bytes2;
     uint8_t *d_s1 = nullptr, *d_s2 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;
@@ -723,23 +761,41 @@ static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *i
         SHARE_TRY(hipMalloc((void **)&d_toff, N * 8));
         SHARE_TRY(hipMalloc((void **)&d_tlen, N * 8));
     }
+    t_alloc = ms_since(t_mark);
+    t_mark = now();
     if (bytes1) SHARE_TRY(hipMemcpyAsync(d_s1, sub.s1, bytes1, hipMemcpyHostToDevice, st));
     if (bytes2) SHARE_TRY(hipMemcpyAsync(d_s2, sub.s2, bytes2, hipMemcpyHostToDevice, st));
     SHARE_TRY(hipMemcpyAsync(d_o1, o1.data(), (N + 1) * 8, hipMemcpyHostToDevice, st));
     SHARE_TRY(hipMemcpyAsync(d_o2, o2.data(), (N + 1) * 8, hipMemcpyHostToDevice, st));
+    if (timing) {
+        SHARE_TRY(hipStreamSynchronize(st));
+        t_h2d = ms_since(t_mark);
+        t_mark = now();
+    }
     rc = bioalign_plan_run(pl, d_s1, d_o1, d_s2, d_o2, d_sc, d_t1, d_t2, d_toff, d_tlen, st);
     if (rc) goto done;
+    if (timing) {
+        SHARE_TRY(hipStreamSynchronize(st));
+        t_kern = ms_since(t_mark);
+        t_mark = now();
+    }
     SHARE_TRY(hipMemcpyAsync(out->scores + lo, d_sc, N * 8, hipMemcpyDeviceToHost, st));
     if (traces) {
-        // the share's slots start at byte b1+b2 of the caller's trace buffers
-        if (cap) {
-            SHARE_TRY(hipMemcpyAsync(out->t1 + b1 + b2, d_t1, cap, hipMemcpyDeviceToHost, st));
-            SHARE_TRY(hipMemcpyAsync(out->t2 + b1 + b2, d_t2, cap, hipMemcpyDeviceToHost, st));
-        }
         toff.resize(N);
         tlen.resize(N);
         SHARE_TRY(hipMemcpyAsync(toff.data(), d_toff, N * 8, hipMemcpyDeviceToHost, st));
         SHARE_TRY(hipMemcpyAsync(tlen.data(), d_tlen, N * 8, hipMemcpyDeviceToHost, st));
+        // the share's part of the caller's trace buffers starts at byte b1+b2; dense layout: the traces fill
+        // its first sum-of-lengths bytes
+        uint64_t used = cap;
+        if (pl->dense) {
+            SHARE_TRY(hipStreamSynchronize(st));
+            used = toff[N - 1] + tlen[N - 1];
+        }
+        if (used) {
+            SHARE_TRY(hipMemcpyAsync(out->t1 + b1 + b2, d_t1, used, hipMemcpyDeviceToHost, st));
+            SHARE_TRY(hipMemcpyAsync(out->t2 + b1 + b2, d_t2, used, hipMemcpyDeviceToHost, st));
+        }
     }
     SHARE_TRY(hipStreamSynchronize(st));
     if (traces)
@@ -747,6 +803,8 @@ static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *i
             out->t_off[lo + p] = toff[p] + b1 + b2;
             out->t_len[lo + p] = tlen[p];
         }
+    t_d2h = ms_since(t_mark);
+    t_mark = now();
 done:
     (void)hipFree(d_s1);
     (void)hipFree(d_s2);
@@ -760,6 +818,9 @@ done:
     if (st) (void)hipStreamDestroy(st);
     // bioalign_plan_destroy touches pl->ctx (== &local), still alive here
     bioalign_plan_destroy(pl);
+    if (timing)
+        fprintf(stderr, "bioalign share dev %d, %llu pairs: plan %.2f ms, alloc %.2f, h2d %.2f, kernels %.2f, d2h %.2f, free %.2f, total %.2f\n",
+                dev_index, (unsigned long long)N, t_plan, t_alloc, t_h2d, t_kern, t_d2h, ms_since(t_mark), ms_since(t_start));
     if (rc) *err = local.err;
     return rc;
 #undef SHARE_TRY

@@ -87,7 +87,9 @@ struct BaTraceParams {
     int64_t *scores;
     uint8_t *t1, *t2;
     uint64_t *t_off, *t_len;
-    void *rec;             // move records (linear-gap walk + expansion), or null: the walk writes bytes itself
+    void *rec;             // move records (linear-gap walk + expansion); null only with score_only
+    const uint64_t *dense_end;  // [n_pairs] by pair: where the pair's trace ends when the traces are laid back to back
+                                // in pair order instead of into the pairs' slots (null: slots)
 };
 
 // ----------------------------------------------------------------------------

@@ -686,7 +686,8 @@ __global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_expand_kernel(BaTracePa
     const BaMoveRec hd = recs[-1];
     const uint32_t p = hd.count;
     const uint64_t len = hd.ops;
-    const uint64_t end = (uint64_t)hd.i | ((uint64_t)hd.j << 32);
+    const bool dense = P.dense_end != nullptr;
+    const uint64_t end = dense ? P.dense_end[p] : ((uint64_t)hd.i | ((uint64_t)hd.j << 32));
     const uint8_t *s1 = P.s1 + P.s1_off[p];
     const uint8_t *s2 = P.s2 + P.s2_off[p];
     const uint32_t nrec = (uint32_t)((len + 15) / 16);
@@ -730,13 +731,16 @@ __global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_expand_kernel(BaTracePa
             b[(15 - k) >> 2] |= y << (((15 - k) & 3) * 8);
         }
         const uint64_t chunk = end - 16ull * (r + 1);
-        if (rr.count == 16 && al1) {
-            *reinterpret_cast<uint4 *>(P.t1 + chunk) = make_uint4(a[0], a[1], a[2], a[3]);
+        if (rr.count == 16 && (al1 || dense)) {
+            // (dense layout: 16-byte stores at whatever alignment the trace's end has -- global memory takes them)
+            const uint4 v = make_uint4(a[0], a[1], a[2], a[3]);
+            __builtin_memcpy(P.t1 + chunk, &v, 16);
         } else {
             for (uint32_t k = 0; k < rr.count; ++k) P.t1[chunk + 15 - k] = (uint8_t)(a[(15 - k) >> 2] >> (((15 - k) & 3) * 8));
         }
-        if (rr.count == 16 && al2) {
-            *reinterpret_cast<uint4 *>(P.t2 + chunk) = make_uint4(b[0], b[1], b[2], b[3]);
+        if (rr.count == 16 && (al2 || dense)) {
+            const uint4 v = make_uint4(b[0], b[1], b[2], b[3]);
+            __builtin_memcpy(P.t2 + chunk, &v, 16);
         } else {
             for (uint32_t k = 0; k < rr.count; ++k) P.t2[chunk + 15 - k] = (uint8_t)(b[(15 - k) >> 2] >> (((15 - k) & 3) * 8));
         }
@@ -803,40 +807,113 @@ extern "C" size_t ba_trace_linear_lds_bytes(int na, int nb, int R, int K, int wa
     return ((size_t)waves * words * 64) * 4;
 }
 
+// Dense trace layout: exclusive / inclusive prefix sums of the trace lengths in pair order.
+//   ba_len_partial: block sums over 2048 lengths;  (one-block scan of the sums: kernels_fasta.hip's fa_scan1)
+//   ba_len_apply:   t_off[p] = sum of the lengths before p, dense_end[p] = t_off[p] + len[p]
+__global__ void __launch_bounds__(256) ba_len_partial_kernel(const uint64_t *len, uint64_t n, uint64_t *part)
+{
+    __shared__ uint64_t sa[4];
+    const uint64_t base = (uint64_t)blockIdx.x * 2048;
+    uint64_t a = 0;
+    for (int k = 0; k < 8; ++k) {
+        const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
+        if (i < n) a += len[i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+    if ((threadIdx.x & 63) == 0) sa[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sa[0] + sa[1] + sa[2] + sa[3];
+}
+
+__global__ void __launch_bounds__(256) ba_len_apply_kernel(const uint64_t *len, uint64_t n, const uint64_t *part,
+                                                           uint64_t *t_off, uint64_t *dense_end)
+{
+    __shared__ uint64_t wa[4];
+    __shared__ uint64_t carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * 2048;
+    if (threadIdx.x == 0) carry = part[blockIdx.x];  // scanned: the lengths before this block
+    __syncthreads();
+    for (int k = 0; k < 8; ++k) {
+        const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
+        const uint64_t v = i < n ? len[i] : 0;
+        uint64_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wa[wave] = inc;
+        __syncthreads();
+        uint64_t pre = carry, tot = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) pre += wa[w];
+            tot += wa[w];
+        }
+        if (i < n) {
+            t_off[i] = pre + inc - v;
+            dense_end[i] = pre + inc;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot;
+        __syncthreads();
+    }
+}
+
+extern "C" hipError_t ba_launch_len_partial(const uint64_t *len, uint64_t n, uint64_t *part, hipStream_t st)
+{
+    hipLaunchKernelGGL(ba_len_partial_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, st, len, n, part);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t ba_launch_len_apply(const uint64_t *len, uint64_t n, const uint64_t *part, uint64_t *t_off,
+                                          uint64_t *dense_end, hipStream_t st)
+{
+    hipLaunchKernelGGL(ba_len_apply_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, st, len, n, part, t_off, dense_end);
+    return hipGetLastError();
+}
+
+enum { BA_TRACE_WALK = 1, BA_TRACE_EXPAND = 2 };
+
 template <int MODE, int R, int K>
-static hipError_t launch_trace(const BaTraceParams &P, hipStream_t st)
+static hipError_t launch_trace(const BaTraceParams &P, int phases, hipStream_t st)
 {
     const int waves = 4;
     const uint32_t nbundles = P.bundle_end - P.bundle_begin;
     const uint32_t blocks = (nbundles + waves - 1) / waves;
     const size_t lds = ba_trace_linear_lds_bytes(P.na, P.nb, R, K, waves);
     if (!P.score_only && !P.rec) return hipErrorInvalidValue;  // the walk records its moves for the expansion
-    hipLaunchKernelGGL((ba_trace_linear_kernel<MODE, R, K>), dim3(blocks), dim3(waves * 64), lds, st, P);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || P.score_only) return e;
+    hipError_t e = hipSuccess;
+    if (phases & BA_TRACE_WALK) {
+        hipLaunchKernelGGL((ba_trace_linear_kernel<MODE, R, K>), dim3(blocks), dim3(waves * 64), lds, st, P);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess || P.score_only || !(phases & BA_TRACE_EXPAND)) return e;
     hipLaunchKernelGGL(ba_expand_kernel, dim3(nbundles), dim3(64 * BA_EXPAND_TPP), 0, st, P);
     return hipGetLastError();
 }
 
 template <int MODE>
-static hipError_t launch_trace_mode(const BaTraceParams &P, int R, int K, hipStream_t st)
+static hipError_t launch_trace_mode(const BaTraceParams &P, int R, int K, int phases, hipStream_t st)
 {
-    if (R == 32 && K == 2) return launch_trace<MODE, 32, 2>(P, st);
-    if (R == 32 && K == 4) return launch_trace<MODE, 32, 4>(P, st);
-    if (R == 16 && K == 2) return launch_trace<MODE, 16, 2>(P, st);
-    if (R == 16 && K == 4) return launch_trace<MODE, 16, 4>(P, st);
-    if (R == 16 && K == 8) return launch_trace<MODE, 16, 8>(P, st);
+    if (R == 32 && K == 2) return launch_trace<MODE, 32, 2>(P, phases, st);
+    if (R == 32 && K == 4) return launch_trace<MODE, 32, 4>(P, phases, st);
+    if (R == 16 && K == 2) return launch_trace<MODE, 16, 2>(P, phases, st);
+    if (R == 16 && K == 4) return launch_trace<MODE, 16, 4>(P, phases, st);
+    if (R == 16 && K == 8) return launch_trace<MODE, 16, 8>(P, phases, st);
     return hipErrorInvalidValue;
 }
 
-extern "C" hipError_t ba_launch_trace_linear(const BaTraceParams &P, int mode, int R, int K, hipStream_t st)
+// phases: 1 = the walk (scores, move records, lengths), 2 = the expansion into bytes, 3 = both
+extern "C" hipError_t ba_launch_trace_linear(const BaTraceParams &P, int mode, int R, int K, int phases, hipStream_t st)
 {
     if (P.bundle_end == P.bundle_begin) return hipSuccess;
     switch (mode) {
-    case BA_GLOBAL: return launch_trace_mode<BA_GLOBAL>(P, R, K, st);
-    case BA_LOCAL: return launch_trace_mode<BA_LOCAL>(P, R, K, st);
-    case BA_FITTING: return launch_trace_mode<BA_FITTING>(P, R, K, st);
-    case BA_OVERLAP: return launch_trace_mode<BA_OVERLAP>(P, R, K, st);
+    case BA_GLOBAL: return launch_trace_mode<BA_GLOBAL>(P, R, K, phases, st);
+    case BA_LOCAL: return launch_trace_mode<BA_LOCAL>(P, R, K, phases, st);
+    case BA_FITTING: return launch_trace_mode<BA_FITTING>(P, R, K, phases, st);
+    case BA_OVERLAP: return launch_trace_mode<BA_OVERLAP>(P, R, K, phases, st);
     }
     return hipErrorInvalidValue;
 }

@@ -40,7 +40,12 @@ enum {
 
 /* flags */
 enum {
-    BIOALIGN_SCORE_ONLY = 1u << 0 /* skip the direction matrix and the traceback */
+    BIOALIGN_SCORE_ONLY = 1u << 0,  /* skip the direction matrix and the traceback */
+    BIOALIGN_DENSE_TRACES = 1u << 1 /* plans: lay the traces back to back in pair order (t_off[p] = sum of the
+                                       lengths before p) instead of into the pairs' slots; honoured for linear gaps
+                                       when the batch runs in one workspace chunk, ignored otherwise -- t_off / t_len
+                                       are right either way.  bioalign_batch lays its results out like this
+                                       whenever it can: what crosses PCIe is then the traces, not their slots. */
 };
 
 /* error codes */
@@ -90,13 +95,13 @@ typedef struct {
 
 /*
  * Results, in caller-allocated buffers.  scores has n_pairs entries (Go int).
- * t1 and t2 each have capacity s1_off[n_pairs] + s2_off[n_pairs] bytes: pair p
- * owns the slot [s1_off[p]+s2_off[p], s1_off[p+1]+s2_off[p+1]) -- the longest
- * possible trace -- and its traces are the t_len[p] bytes starting at t_off[p]
- * inside that slot (towards the slot's end: the traceback produces them back to
- * front, so no reversal pass is needed; read them through t_off / t_len, the
- * exact placement inside the slot is the library's).  t_len[p] == 0 is the
- * reference's nil trace.
+ * t1 and t2 each have capacity s1_off[n_pairs] + s2_off[n_pairs] bytes (the sum
+ * of the longest possible traces).  The traces of pair p are the t_len[p] bytes
+ * starting at t_off[p] of t1 and of t2; WHERE in the buffers they lie is the
+ * library's choice -- inside the pair's own slot
+ * [s1_off[p]+s2_off[p], s1_off[p+1]+s2_off[p+1]), or back to back in pair order
+ * (BIOALIGN_DENSE_TRACES) -- so read them through t_off / t_len only.
+ * t_len[p] == 0 is the reference's nil trace.
  * With BIOALIGN_SCORE_ONLY, t1/t2/t_off/t_len may be NULL.
  */
 typedef struct {

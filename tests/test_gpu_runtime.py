@@ -120,3 +120,36 @@ def test_share_pack_between_modes():
         other.share_pack(plans["global"])
     with pytest.raises(Exception, match="does not pack"):
         other.share_pack(plans["local"])
+
+
+def test_dense_trace_layout():
+    # BIOALIGN_DENSE_TRACES: the traces lie back to back in pair order; same traces as the slot layout.
+    # bioalign_batch asks for it by itself: its t_off must be the running sum of its t_len.
+    import torch
+
+    s1, o1, s2, o2 = _ragged(3000, 31)
+    table, c1, c2 = synth.dna_table(1, -1)
+    eng = _native.Engine([0])
+    for mode in ("global", "local"):
+        res = _batch(mode, s1, o1, s2, o2, eng=eng)
+        sc, t1, t2, toff, tlen = res
+        assert np.array_equal(toff, np.concatenate([[0], np.cumsum(tlen)[:-1]]).astype(np.uint64)), mode
+        dev = torch.device("cuda:0")
+        d = [torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(dev) for a in (s1, o1, s2, o2)]
+        N = len(o1) - 1
+        got = {}
+        for flags in (0, _native.DENSE_TRACES):
+            pb = _native.PackedBatch(s1, o1, s2, o2, mode, table, c1, c2, 1, 1, flags=flags)
+            plan = eng.plan(pb)
+            cap = pb.trace_capacity
+            o = dict(sc=torch.empty(N, dtype=torch.int64, device=dev), t1=torch.zeros(cap + 16, dtype=torch.uint8, device=dev),
+                     t2=torch.zeros(cap + 16, dtype=torch.uint8, device=dev), toff=torch.empty(N, dtype=torch.int64, device=dev),
+                     tlen=torch.empty(N, dtype=torch.int64, device=dev))
+            plan.run(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), o["sc"].data_ptr(), o["t1"].data_ptr(),
+                     o["t2"].data_ptr(), o["toff"].data_ptr(), o["tlen"].data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got[flags] = _traces(tuple(o[k].cpu().numpy() for k in ("sc", "t1", "t2", "toff", "tlen")))
+            if flags:
+                tl = o["tlen"].cpu().numpy()
+                assert np.array_equal(o["toff"].cpu().numpy(), np.concatenate([[0], np.cumsum(tl)[:-1]]))
+        assert got[0] == got[_native.DENSE_TRACES] == _traces(res), mode

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""End to end through bioalign_batch (host buffers in, host buffers out: H2D, plan, kernels, D2H), configs[1] shapes.
+   python tools/bench_e2e.py [--pairs 1000000] [--len 150] [--mode global] [--reps 3]"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa: F401  (loads its HIP runtime first, see bio_amd/_native.py)
+from bio_amd import _native, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--pairs", type=int, default=1_000_000)
+ap.add_argument("--len", type=int, default=150)
+ap.add_argument("--mode", default="global")
+ap.add_argument("--reps", type=int, default=3)
+args = ap.parse_args()
+N, L = args.pairs, args.len
+s1, o1, s2, o2 = synth.dna_pairs(N, L, L, config=2)
+table, c1, c2 = synth.dna_table(1, -1)
+ap_dev = [0] * int(os.environ.get("E2E_SHARES", "1"))
+eng = _native.Engine(ap_dev)
+pb = _native.PackedBatch(s1, o1, s2, o2, args.mode, table, c1, c2, 1, 1)
+best = None
+first = None
+out = None
+for r in range(args.reps):
+    t0 = time.perf_counter()
+    out = eng.batch(pb, out=out)  # from the second call on: the same (already touched) output buffers
+    dt = time.perf_counter() - t0
+    if first is None:
+        first = dt
+    else:
+        best = dt if best is None else min(best, dt)
+scores, t1, t2, toff, tlen = out
+best = best if best is not None else first
+cells = N * L * L
+print(json.dumps({"workload": f"{N} pairs x {L} bp, {args.mode}, bioalign_batch host to host", "ms": round(best * 1e3, 2), "first_call_ms_fresh_buffers": round(first * 1e3, 2),
+                  "gcups_end_to_end": round(cells / best / 1e9, 1), "bytes_in": int(s1.size + s2.size),
+                  "bytes_out": int(2 * tlen.sum() + 8 * 3 * N), "score_checksum": int(scores.sum())}))
