@@ -17,11 +17,11 @@ args = ap.parse_args()
 N, L = args.pairs, args.len
 s1, o1, s2, o2 = synth.dna_pairs(N, L, L, config=2)
 table, c1, c2 = synth.dna_table(1, -1)
-ap_dev = [0] * int(os.environ.get("E2E_SHARES", "1"))
-eng = _native.Engine(ap_dev)
+eng = _native.Engine([0])
 pb = _native.PackedBatch(s1, o1, s2, o2, args.mode, table, c1, c2, 1, 1)
 best = None
 first = None
+times = []
 out = None
 for r in range(args.reps):
     t0 = time.perf_counter()
@@ -31,9 +31,10 @@ for r in range(args.reps):
         first = dt
     else:
         best = dt if best is None else min(best, dt)
+        times.append(round(dt * 1e3, 1))
 scores, t1, t2, toff, tlen = out
 best = best if best is not None else first
 cells = N * L * L
-print(json.dumps({"workload": f"{N} pairs x {L} bp, {args.mode}, bioalign_batch host to host", "ms": round(best * 1e3, 2), "first_call_ms_fresh_buffers": round(first * 1e3, 2),
+print(json.dumps({"workload": f"{N} pairs x {L} bp, {args.mode}, bioalign_batch host to host", "ms": round(best * 1e3, 2), "all_ms": times, "first_call_ms_fresh_buffers": round(first * 1e3, 2),
                   "gcups_end_to_end": round(cells / best / 1e9, 1), "bytes_in": int(s1.size + s2.size),
                   "bytes_out": int(2 * tlen.sum() + 8 * 3 * N), "score_checksum": int(scores.sum())}))
