@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <chrono>
@@ -45,8 +47,80 @@ std::string vfmt(const char *fmt, va_list ap)
 
 }  // namespace
 
+// Device memory that bioalign_batch keeps between calls (its workspace and staging buffers are the same sizes
+// call after call; hipMalloc / hipFree of GBs cost milliseconds each way).  At most `cap` bytes are kept while
+// unused (BIOALIGN_POOL_BYTES, default 64 GiB); everything goes back at bioalign_destroy.  Plans that callers
+// create themselves do not use it: their memory is theirs to free.
+struct DevPool {
+    struct Blk {
+        void *p;
+        size_t bytes;
+        int dev;
+        bool used;
+    };
+    std::mutex mu;
+    std::vector<Blk> blks;
+    size_t cap = 64ull << 30;
+    // a block of the device of at least `bytes` (and not wastefully larger), or a new one; null: out of memory
+    void *get(int dev, size_t bytes)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            Blk *best = nullptr;
+            for (Blk &b : blks)
+                if (!b.used && b.dev == dev && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + 4096 &&
+                    (!best || b.bytes < best->bytes))
+                    best = &b;
+            if (best) {
+                best->used = true;
+                return best->p;
+            }
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            trim(0);  // give back what lies unused and try once more
+            if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        }
+        std::lock_guard<std::mutex> g(mu);
+        blks.push_back({p, bytes, dev, true});
+        return p;
+    }
+    void put(void *p)
+    {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (Blk &b : blks)
+                if (b.p == p) b.used = false;
+        }
+        trim(cap);
+    }
+    // frees unused blocks, largest first, until at most `keep` bytes lie unused
+    void trim(size_t keep)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (;;) {
+            size_t idle = 0;
+            long big = -1;
+            for (size_t k = 0; k < blks.size(); ++k)
+                if (!blks[k].used) {
+                    idle += blks[k].bytes;
+                    if (big < 0 || blks[k].bytes > blks[(size_t)big].bytes) big = (long)k;
+                }
+            if (idle <= keep || big < 0) return;
+            (void)hipFree(blks[(size_t)big].p);
+            blks.erase(blks.begin() + big);
+        }
+    }
+    ~DevPool()
+    {
+        for (Blk &b : blks) (void)hipFree(b.p);
+    }
+};
+
 struct bioalign_ctx {
     std::vector<int> devices;
+    std::shared_ptr<DevPool> pool;  // bioalign_batch's device memory (see DevPool)
     std::string err;
     int code = 0;  // code of the last failure
     int fail(int c, const char *fmt, ...)
@@ -116,6 +190,7 @@ struct bioalign_plan {
     std::vector<hipEvent_t> ev_slice;
     hipEvent_t ev_side_done = nullptr;
     std::vector<void *> allocs;
+    std::shared_ptr<DevPool> pool;  // set: the plan's memory comes from (and goes back to) bioalign_batch's pool
 };
 
 namespace {
@@ -123,9 +198,14 @@ namespace {
 int dev_alloc(bioalign_plan *pl, void **p, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess)
-        return pl->ctx->fail(BIOALIGN_ENOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    if (pl->pool) {
+        *p = pl->pool->get(pl->ctx->devices[pl->device], bytes);
+        if (!*p) return pl->ctx->fail(BIOALIGN_ENOMEM, "hipMalloc of %zu bytes failed", bytes);
+    } else {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e != hipSuccess)
+            return pl->ctx->fail(BIOALIGN_ENOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    }
     pl->allocs.push_back(*p);
     pl->ws_bytes += bytes;
     return 0;
@@ -175,6 +255,8 @@ extern "C" bioalign_ctx *bioalign_create(const int *device_ids, int n_devices)
             ctx->devices.push_back(device_ids[i]);
         }
     }
+    ctx->pool = std::make_shared<DevPool>();
+    ctx->pool->cap = env_u64("BIOALIGN_POOL_BYTES", 64ull << 30);
     return ctx;
 }
 
@@ -191,7 +273,12 @@ extern "C" void bioalign_plan_destroy(bioalign_plan *pl)
 {
     if (!pl) return;
     (void)hipSetDevice(pl->ctx->devices[pl->device]);
-    for (void *p : pl->allocs) (void)hipFree(p);
+    for (void *p : pl->allocs) {
+        if (pl->pool)
+            pl->pool->put(p);
+        else
+            (void)hipFree(p);
+    }
     for (hipEvent_t e : pl->ev0) (void)hipEventDestroy(e);
     for (hipEvent_t e : pl->ev1) (void)hipEventDestroy(e);
     for (hipEvent_t e : pl->ev_slice) (void)hipEventDestroy(e);
@@ -728,8 +815,18 @@ static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *i
     sub.s2_off = o2.data();
     sub.n_pairs = N;
     sub.flags |= BIOALIGN_DENSE_TRACES;  // where the plan can: only the traces themselves go back over PCIe
-    bioalign_plan *pl = bioalign_plan_create(&local, dev_index, &sub);
-    if (!pl) return fail(local.code ? local.code : BIOALIGN_EINVAL);
+    // (a plan of bioalign_batch's own: its memory comes from the context's pool)
+    const std::shared_ptr<DevPool> pool = ctx->pool;
+    const int hip_dev = ctx->devices[dev_index];
+    if (hipSetDevice(hip_dev) != hipSuccess) return fail(local.fail(BIOALIGN_EHIP, "hipSetDevice failed"));
+    bioalign_plan *pl = new bioalign_plan;
+    pl->ctx = &local;
+    pl->device = dev_index;
+    pl->pool = pool;
+    if (plan_build(pl, &sub) != 0) {
+        bioalign_plan_destroy(pl);
+        return fail(local.code ? local.code : BIOALIGN_EINVAL);
+    }
     t_plan = ms_since(t_start);
     auto t_mark = now();
     const bool traces = !pl->score_only;
@@ -750,17 +847,26 @@ static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *i
     } while (0)
     SHARE_TRY(hipSetDevice(ctx->devices[dev_index]));
     SHARE_TRY(hipStreamCreate(&st));
-    SHARE_TRY(hipMalloc((void **)&d_s1, bytes1 + 16));
-    SHARE_TRY(hipMalloc((void **)&d_s2, bytes2 + 16));
-    SHARE_TRY(hipMalloc((void **)&d_o1, (N + 1) * 8));
-    SHARE_TRY(hipMalloc((void **)&d_o2, (N + 1) * 8));
-    SHARE_TRY(hipMalloc((void **)&d_sc, N * 8));
+#define SHARE_GET(ptr, bytes)                                                                \
+    do {                                                                                     \
+        *(void **)&(ptr) = pool->get(hip_dev, (bytes));                                      \
+        if (!(ptr)) {                                                                        \
+            rc = local.fail(BIOALIGN_ENOMEM, "hipMalloc of %zu bytes failed", (size_t)(bytes)); \
+            goto done;                                                                       \
+        }                                                                                    \
+    } while (0)
+    SHARE_GET(d_s1, bytes1 + 16);
+    SHARE_GET(d_s2, bytes2 + 16);
+    SHARE_GET(d_o1, (N + 1) * 8);
+    SHARE_GET(d_o2, (N + 1) * 8);
+    SHARE_GET(d_sc, N * 8);
     if (traces) {
-        SHARE_TRY(hipMalloc((void **)&d_t1, cap + 16));
-        SHARE_TRY(hipMalloc((void **)&d_t2, cap + 16));
-        SHARE_TRY(hipMalloc((void **)&d_toff, N * 8));
-        SHARE_TRY(hipMalloc((void **)&d_tlen, N * 8));
+        SHARE_GET(d_t1, cap + 16);
+        SHARE_GET(d_t2, cap + 16);
+        SHARE_GET(d_toff, N * 8);
+        SHARE_GET(d_tlen, N * 8);
     }
+#undef SHARE_GET
     t_alloc = ms_since(t_mark);
     t_mark = now();
     if (bytes1) SHARE_TRY(hipMemcpyAsync(d_s1, sub.s1, bytes1, hipMemcpyHostToDevice, st));
@@ -806,15 +912,16 @@ static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *i
     t_d2h = ms_since(t_mark);
     t_mark = now();
 done:
-    (void)hipFree(d_s1);
-    (void)hipFree(d_s2);
-    (void)hipFree(d_o1);
-    (void)hipFree(d_o2);
-    (void)hipFree(d_sc);
-    (void)hipFree(d_t1);
-    (void)hipFree(d_t2);
-    (void)hipFree(d_toff);
-    (void)hipFree(d_tlen);
+    if (st) (void)hipStreamSynchronize(st);  // nothing of this share still runs on memory that goes back to the pool
+    pool->put(d_s1);
+    pool->put(d_s2);
+    pool->put(d_o1);
+    pool->put(d_o2);
+    pool->put(d_sc);
+    pool->put(d_t1);
+    pool->put(d_t2);
+    pool->put(d_toff);
+    pool->put(d_tlen);
     if (st) (void)hipStreamDestroy(st);
     // bioalign_plan_destroy touches pl->ctx (== &local), still alive here
     bioalign_plan_destroy(pl);
