@@ -18,6 +18,7 @@ GLOBAL, LOCAL, FITTING, OVERLAP = 0, 1, 2, 3
 MODES = {"global": GLOBAL, "local": LOCAL, "fitting": FITTING, "overlap": OVERLAP}
 SCORE_ONLY = 1
 DENSE_TRACES = 2  # plans: traces back to back in pair order instead of in per-pair slots
+TRACE_OPS = 4     # compact move records in t1 instead of the two gapped strings (include/bioalign.h)
 EINVAL, ENODEVICE, ENOMEM, EHIP, EUNSUPPORTED = -1, -2, -3, -4, -5
 
 # every symbol include/bioalign.h declares
@@ -36,6 +37,8 @@ EXPORTS = (
     "bioalign_plan_run",
     "bioalign_plan_share_pack",
     "bioalign_plan_dp_ms",
+    "bioalign_ops_capacity",
+    "bioalign_expand_ops",
     "bioalign_fasta_parse",
     "bioalign_fasta_destroy",
     "bioalign_fasta_count",
@@ -135,6 +138,11 @@ def lib():
         L.bioalign_plan_run.argtypes = [C.c_void_p] + [C.c_void_p] * 9 + [C.c_void_p]
         L.bioalign_plan_share_pack.restype = C.c_int
         L.bioalign_plan_share_pack.argtypes = [C.c_void_p, C.c_void_p]
+        L.bioalign_ops_capacity.restype = C.c_uint64
+        L.bioalign_ops_capacity.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.bioalign_expand_ops.restype = C.c_int
+        L.bioalign_expand_ops.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint8,
+                                          C.c_void_p, C.c_void_p]
         L.bioalign_fasta_parse.restype = C.c_void_p
         L.bioalign_fasta_parse.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int]
         L.bioalign_fasta_destroy.argtypes = [C.c_void_p]
@@ -258,12 +266,19 @@ class Engine:
         cap = pb.trace_capacity
         if out is not None:
             scores, t1, t2, t_off, t_len = out
-            if len(scores) < n or len(t1) < cap or len(t2) < cap or len(t_off) < n or len(t_len) < n:
+            need1 = int(lib().bioalign_ops_capacity(n, int(pb.s1_off[-1]), int(pb.s2_off[-1]))) if pb.c.flags & TRACE_OPS else cap
+            need2 = 0 if pb.c.flags & TRACE_OPS else cap
+            if len(scores) < n or len(t1) < need1 or len(t2) < need2 or len(t_off) < n or len(t_len) < n:
                 raise ValueError("output buffers too small for this batch")
         else:
             scores = np.zeros(max(n, 1), dtype=np.int64)
-            t1 = np.zeros(cap + 1, dtype=np.uint8)
-            t2 = np.zeros(cap + 1, dtype=np.uint8)
+            if pb.c.flags & TRACE_OPS:  # compact records: t1 only, sized by the library's rule
+                cap1 = int(lib().bioalign_ops_capacity(n, int(pb.s1_off[-1]), int(pb.s2_off[-1])))
+                t1 = np.zeros(cap1 + 1, dtype=np.uint8)
+                t2 = np.zeros(1, dtype=np.uint8)
+            else:
+                t1 = np.zeros(cap + 1, dtype=np.uint8)
+                t2 = np.zeros(cap + 1, dtype=np.uint8)
             t_off = np.zeros(max(n, 1), dtype=np.uint64)
             t_len = np.zeros(max(n, 1), dtype=np.uint64)
         r = Result()
@@ -441,3 +456,17 @@ class Fasta:
             self.close()
         except Exception:
             pass
+
+
+def expand_ops(s1: bytes, s2: bytes, t1: np.ndarray, t_off: int, moves: int, gap_symbol: int = ord("-")):
+    """One pair's compact record (TRACE_OPS) -> the reference's two gapped strings (bioalign_expand_ops)."""
+    a = np.frombuffer(bytes(s1) or b"\0", dtype=np.uint8)
+    b = np.frombuffer(bytes(s2) or b"\0", dtype=np.uint8)
+    o1 = np.zeros(max(moves, 1), dtype=np.uint8)
+    o2 = np.zeros(max(moves, 1), dtype=np.uint8)
+    rec = np.ascontiguousarray(t1[int(t_off):int(t_off) + 8 + 4 * ((int(moves) + 15) // 16)])
+    rc = lib().bioalign_expand_ops(a.ctypes.data, len(s1), b.ctypes.data, len(s2), rec.ctypes.data, int(moves), gap_symbol,
+                                   o1.ctypes.data, o2.ctypes.data)
+    if rc != 0:
+        raise BioAlignError(rc, "malformed compact trace record")
+    return o1[:moves].tobytes(), o2[:moves].tobytes()

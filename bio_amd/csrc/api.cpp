@@ -30,6 +30,8 @@ extern "C" hipError_t ba_launch_len_partial(const uint64_t *len, uint64_t n, uin
 extern "C" hipError_t ba_launch_len_apply(const uint64_t *len, uint64_t n, const uint64_t *part, uint64_t *t_off,
                                           uint64_t *dense_end, hipStream_t st);
 extern "C" hipError_t ba_launch_fasta_scan1(uint64_t *a, uint64_t *b, uint64_t n, uint64_t *tot, hipStream_t st);
+extern "C" hipError_t ba_launch_ops_sizes(const uint64_t *t_len, uint64_t n, uint64_t *sizes, hipStream_t st);
+extern "C" hipError_t ba_launch_ops_emit(const BaTraceParams &P, hipStream_t st);
 extern "C" size_t ba_dp_affine_lds_bytes(int nb, int nb4, int na_pad, int R, int waves, int nib);
 extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, int waves, int pipe, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_affine(const BaTraceParams &P, int mode, int R, hipStream_t st);
@@ -177,6 +179,8 @@ struct bioalign_plan {
     void *d_rec = nullptr;  // move records of the linear-gap walk (16 bytes per 16 trace columns)
     // dense trace layout (bioalign_batch: what goes back over PCIe is the traces, not their slots)
     bool want_dense = false, dense = false;
+    bool ops = false;  // BIOALIGN_TRACE_OPS: compact move records instead of the two strings
+    uint64_t *d_sizes = nullptr;
     uint64_t *d_dense_end = nullptr, *d_len_part = nullptr;
     BaLocalBest *d_best = nullptr;
     uint64_t ws_bytes = 0;
@@ -306,6 +310,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     pl->affine = in->gap_open != in->gap_extend;
     pl->score_only = (in->flags & BIOALIGN_SCORE_ONLY) != 0;
     pl->want_dense = (in->flags & BIOALIGN_DENSE_TRACES) != 0;
+    pl->ops = !pl->score_only && (in->flags & BIOALIGN_TRACE_OPS) != 0;
     pl->gap = pl->gap_open = in->gap_open;
     pl->gap_ext = in->gap_extend;
     pl->gap_symbol = in->gap_symbol;
@@ -508,7 +513,10 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     if (use_rec && (rc = dev_alloc(pl, &pl->d_rec, m_rec * 16))) return rc;
     // dense layout: the walks of the whole batch come first, then one scan of the lengths, then the expansion --
     // which needs every pair's move records at once: one chunk, linear gaps
-    pl->dense = pl->want_dense && use_rec && pl->chunks.size() == 1;
+    if (pl->ops && (!use_rec || pl->chunks.size() != 1))
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "BIOALIGN_TRACE_OPS needs linear gaps and a batch that runs in one workspace chunk");
+    pl->dense = (pl->want_dense || pl->ops) && use_rec && pl->chunks.size() == 1;
+    if (pl->ops && (rc = dev_alloc(pl, (void **)&pl->d_sizes, N * 8))) return rc;
     if (pl->dense) {
         if ((rc = dev_alloc(pl, (void **)&pl->d_dense_end, N * 8))) return rc;
         if ((rc = dev_alloc(pl, (void **)&pl->d_len_part, ((N + 2047) / 2048 + 2) * 8))) return rc;
@@ -611,7 +619,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
     if (pl->n_pairs == 0) return 0;
     if (!d_s1_off || !d_s2_off || !d_scores)
         return ctx->fail(BIOALIGN_EINVAL, "null device pointer");
-    if (!pl->score_only && (!d_t1 || !d_t2 || !d_t_off || !d_t_len))
+    if (!pl->score_only && (!d_t1 || (!d_t2 && !pl->ops) || !d_t_off || !d_t_len))
         return ctx->fail(BIOALIGN_EINVAL, "trace buffers are required unless BIOALIGN_SCORE_ONLY is set");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(ctx, hipSetDevice(ctx->devices[pl->device]));
@@ -719,11 +727,20 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
                 // walk -> prefix sums of the lengths in pair order -> expansion to the dense places
                 HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 1, ts));
                 const uint64_t nparts = (pl->n_pairs + 2047) / 2048;
-                HIP_TRY(ctx, ba_launch_len_partial(d_t_len, pl->n_pairs, pl->d_len_part, ts));
+                // what is laid back to back: the traces themselves, or (BIOALIGN_TRACE_OPS) the compact records
+                const uint64_t *lens = d_t_len;
+                if (pl->ops) {
+                    HIP_TRY(ctx, ba_launch_ops_sizes(d_t_len, pl->n_pairs, pl->d_sizes, ts));
+                    lens = pl->d_sizes;
+                }
+                HIP_TRY(ctx, ba_launch_len_partial(lens, pl->n_pairs, pl->d_len_part, ts));
                 HIP_TRY(ctx, ba_launch_fasta_scan1(pl->d_len_part, nullptr, nparts, pl->d_len_part + nparts, ts));
-                HIP_TRY(ctx, ba_launch_len_apply(d_t_len, pl->n_pairs, pl->d_len_part, d_t_off, pl->d_dense_end, ts));
+                HIP_TRY(ctx, ba_launch_len_apply(lens, pl->n_pairs, pl->d_len_part, d_t_off, pl->d_dense_end, ts));
                 tr.dense_end = pl->d_dense_end;
-                HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 2, ts));
+                if (pl->ops)
+                    HIP_TRY(ctx, ba_launch_ops_emit(tr, ts));
+                else
+                    HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 2, ts));
             }
         }
         if (slices > 1) {
@@ -831,6 +848,10 @@ static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *i
     auto t_mark = now();
     const bool traces = !pl->score_only;
     const uint64_t bytes1 = o1[N], bytes2 = o2[N], cap = bytes1 + bytes2;
+    const bool ops = pl->ops;
+    // BIOALIGN_TRACE_OPS: the share's records go to the caller's t1 from byte ops_base(lo) on (see bioalign_ops_capacity)
+    auto ops_base = [&](uint64_t p) { return 16 * p + 4 * ((in->s1_off[p] + in->s2_off[p]) / 16); };
+    const uint64_t t1_bytes = ops ? ops_base(hi) - ops_base(lo) : cap;
     uint8_t *d_s1 = nullptr, *d_s2 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;
     uint64_t *d_o1 = nullptr, *d_o2 = nullptr, *d_toff = nullptr, *d_tlen = nullptr;
     int64_t *d_sc = nullptr;
@@ -861,8 +882,8 @@ static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *i
     SHARE_GET(d_o2, (N + 1) * 8);
     SHARE_GET(d_sc, N * 8);
     if (traces) {
-        SHARE_GET(d_t1, cap + 16);
-        SHARE_GET(d_t2, cap + 16);
+        SHARE_GET(d_t1, t1_bytes + 16);
+        if (!ops) SHARE_GET(d_t2, cap + 16);
         SHARE_GET(d_toff, N * 8);
         SHARE_GET(d_tlen, N * 8);
     }
@@ -896,9 +917,15 @@ static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *i
         uint64_t used = cap;
         if (pl->dense) {
             SHARE_TRY(hipStreamSynchronize(st));
-            used = toff[N - 1] + tlen[N - 1];
+            used = toff[N - 1] + (ops ? 8 + 4 * ((tlen[N - 1] + 15) / 16) : tlen[N - 1]);
         }
-        if (used) {
+        if (ops) {
+            if (used > t1_bytes) {
+                rc = local.fail(BIOALIGN_EHIP, "compact records exceed their capacity");
+                goto done;
+            }
+            SHARE_TRY(hipMemcpyAsync(out->t1 + ops_base(lo), d_t1, used, hipMemcpyDeviceToHost, st));
+        } else if (used) {
             SHARE_TRY(hipMemcpyAsync(out->t1 + b1 + b2, d_t1, used, hipMemcpyDeviceToHost, st));
             SHARE_TRY(hipMemcpyAsync(out->t2 + b1 + b2, d_t2, used, hipMemcpyDeviceToHost, st));
         }
@@ -906,7 +933,7 @@ static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *i
     SHARE_TRY(hipStreamSynchronize(st));
     if (traces)
         for (uint64_t p = 0; p < N; ++p) {
-            out->t_off[lo + p] = toff[p] + b1 + b2;
+            out->t_off[lo + p] = toff[p] + (ops ? ops_base(lo) : b1 + b2);
             out->t_len[lo + p] = tlen[p];
         }
     t_d2h = ms_since(t_mark);
@@ -942,7 +969,7 @@ extern "C" int bioalign_batch(bioalign_ctx *ctx, const bioalign_batch_t *in, bio
     if (N == 0) return 0;
     if (!out->scores) return ctx->fail(BIOALIGN_EINVAL, "null scores buffer");
     const bool traces = !(in->flags & BIOALIGN_SCORE_ONLY);
-    if (traces && (!out->t1 || !out->t2 || !out->t_off || !out->t_len))
+    if (traces && (!out->t1 || (!out->t2 && !(in->flags & BIOALIGN_TRACE_OPS)) || !out->t_off || !out->t_len))
         return ctx->fail(BIOALIGN_EINVAL, "trace buffers are required unless BIOALIGN_SCORE_ONLY is set");
     if ((in->s1_off[N] && !in->s1) || (in->s2_off[N] && !in->s2))
         return ctx->fail(BIOALIGN_EINVAL, "null sequence bytes");
@@ -1702,5 +1729,46 @@ extern "C" int bioalign_fasta_copy_seq(const bioalign_fasta *F, uint8_t *dst)
     if (!dst && F->total) return ctx->fail(BIOALIGN_EINVAL, "null destination");
     HIP_TRY(ctx, hipSetDevice(ctx->devices[F->dev]));
     if (F->total) HIP_TRY(ctx, hipMemcpy(dst, F->seq.p, F->total, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ----------------------------------------------------------------------------
+// Compact traces (BIOALIGN_TRACE_OPS): capacity, and the host-side expansion of one record into the reference's
+// two gapped strings (align.go:126-143; align_pair.go:197-216).  Format conversion of O(trace) bytes, no DP.
+// ----------------------------------------------------------------------------
+extern "C" uint64_t bioalign_ops_capacity(uint64_t n_pairs, uint64_t total_s1, uint64_t total_s2)
+{
+    return 16 * n_pairs + 4 * ((total_s1 + total_s2) / 16) + 16;
+}
+
+extern "C" int bioalign_expand_ops(const uint8_t *s1, uint64_t n, const uint8_t *s2, uint64_t m, const uint8_t *record,
+                                   uint64_t moves, uint8_t gap_symbol, uint8_t *t1_out, uint8_t *t2_out)
+{
+    if (!record || (moves && (!t1_out || !t2_out))) return BIOALIGN_EINVAL;
+    uint32_t ij[2];
+    memcpy(ij, record, 8);
+    uint64_t i = ij[0], j = ij[1];
+    if (i > n || j > m) return BIOALIGN_EINVAL;
+    for (uint64_t k = 0; k < moves; ++k) {
+        uint32_t w;
+        memcpy(&w, record + 8 + 4 * (k / 16), 4);
+        const uint32_t mv = (w >> (2 * (k % 16))) & 3u;
+        const uint64_t pos = moves - 1 - k;  // the first move is the last column
+        if (mv == 0) {
+            if (i == 0) return BIOALIGN_EINVAL;
+            t1_out[pos] = s1[--i];
+            t2_out[pos] = gap_symbol;
+        } else if (mv == 1) {
+            if (j == 0) return BIOALIGN_EINVAL;
+            t1_out[pos] = gap_symbol;
+            t2_out[pos] = s2[--j];
+        } else if (mv == 2) {
+            if (i == 0 || j == 0) return BIOALIGN_EINVAL;
+            t1_out[pos] = s1[--i];
+            t2_out[pos] = s2[--j];
+        } else {
+            return BIOALIGN_EINVAL;
+        }
+    }
     return 0;
 }

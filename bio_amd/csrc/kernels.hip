@@ -874,6 +874,49 @@ extern "C" hipError_t ba_launch_len_apply(const uint64_t *len, uint64_t n, const
     return hipGetLastError();
 }
 
+// Compact trace output (BIOALIGN_TRACE_OPS): per pair a record of 8 + 4 * ceil(len / 16) bytes
+// -- the end cell (i, j) as two uint32, then the walk's 2-bit move codes, 16 to a dword, first move = last column
+// of the alignment -- laid back to back in pair order.  ba_ops_sizes: record sizes from the trace lengths (the
+// prefix sums are ba_len_partial / fa_scan1 / ba_len_apply); ba_ops_emit: the records themselves.
+__global__ void __launch_bounds__(256) ba_ops_sizes_kernel(const uint64_t *t_len, uint64_t n, uint64_t *sizes)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) sizes[i] = 8 + 4 * ((t_len[i] + 15) / 16);
+}
+
+__global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_ops_emit_kernel(BaTraceParams P)
+{
+    const uint32_t b_idx = P.bundle_begin + blockIdx.x;
+    if (b_idx >= P.bundle_end) return;
+    const BaBundle B = P.bundles[b_idx];
+    const uint32_t q = threadIdx.x / BA_EXPAND_TPP, g16 = threadIdx.x % BA_EXPAND_TPP;
+    if (q >= B.count) return;
+    const BaMoveRec *recs = reinterpret_cast<const BaMoveRec *>(P.rec) + B.rec_off + (size_t)q * B.rec_cap + 1;
+    const BaMoveRec hd = recs[-1];
+    const uint32_t p = hd.count;
+    const uint32_t nrec = (uint32_t)(((uint64_t)hd.ops + 15) / 16);
+    uint32_t *out = reinterpret_cast<uint32_t *>(P.t1 + P.t_off[p]);  // record offsets are multiples of 4
+    if (g16 == 0) {
+        out[0] = nrec ? recs[0].i : 0u;  // the cell the first move leaves: the end cell of the alignment
+        out[1] = nrec ? recs[0].j : 0u;
+    }
+    for (uint32_t r = g16; r < nrec; r += BA_EXPAND_TPP) out[2 + r] = recs[r].ops;
+}
+
+extern "C" hipError_t ba_launch_ops_sizes(const uint64_t *t_len, uint64_t n, uint64_t *sizes, hipStream_t st)
+{
+    hipLaunchKernelGGL(ba_ops_sizes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t_len, n, sizes);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t ba_launch_ops_emit(const BaTraceParams &P, hipStream_t st)
+{
+    const uint32_t nbundles = P.bundle_end - P.bundle_begin;
+    if (nbundles == 0) return hipSuccess;
+    hipLaunchKernelGGL(ba_ops_emit_kernel, dim3(nbundles), dim3(64 * BA_EXPAND_TPP), 0, st, P);
+    return hipGetLastError();
+}
+
 enum { BA_TRACE_WALK = 1, BA_TRACE_EXPAND = 2 };
 
 template <int MODE, int R, int K>

@@ -41,11 +41,20 @@ enum {
 /* flags */
 enum {
     BIOALIGN_SCORE_ONLY = 1u << 0,  /* skip the direction matrix and the traceback */
-    BIOALIGN_DENSE_TRACES = 1u << 1 /* plans: lay the traces back to back in pair order (t_off[p] = sum of the
+    BIOALIGN_DENSE_TRACES = 1u << 1,/* plans: lay the traces back to back in pair order (t_off[p] = sum of the
                                        lengths before p) instead of into the pairs' slots; honoured for linear gaps
                                        when the batch runs in one workspace chunk, ignored otherwise -- t_off / t_len
                                        are right either way.  bioalign_batch lays its results out like this
                                        whenever it can: what crosses PCIe is then the traces, not their slots. */
+    BIOALIGN_TRACE_OPS = 1u << 2    /* instead of the two gapped strings, t1 receives one compact record per pair (t2
+                                       is not touched and may be NULL): uint32 i, uint32 j -- the cell the alignment
+                                       ends in -- then the moves of the traceback, 2 bits each (0: s1[i-1] against a
+                                       gap, i -= 1; 1: a gap against s2[j-1], j -= 1; 2: s1[i-1] against s2[j-1], both
+                                       -= 1), first move = LAST column of the alignment, 16 moves per little-endian
+                                       uint32.  t_off[p] = byte offset of the pair's record in t1, t_len[p] = number
+                                       of moves.  t1 needs bioalign_ops_capacity() bytes.  bioalign_expand_ops() turns
+                                       a record into the reference's two strings.  Linear gaps, batches that run in
+                                       one workspace chunk; anything else answers BIOALIGN_EUNSUPPORTED. */
 };
 
 /* error codes */
@@ -214,6 +223,15 @@ int bioalign_stripe_dp(bioalign_stripe *stripe, const int32_t *d_left_col, int32
 int bioalign_stripe_end_cell(bioalign_stripe *stripe, int64_t *true_score, uint64_t *j_local, int64_t *score);
 int bioalign_stripe_walk(bioalign_stripe *stripe, uint64_t i, uint64_t j_local, uint8_t *t1, uint8_t *t2,
                          uint64_t *len, uint64_t *exit_i, uint64_t *exit_j);
+
+/*
+ * Compact traces (BIOALIGN_TRACE_OPS; no counterpart in the reference, whose callers get the two gapped strings of
+ * align.go:126-144): bytes t1 must hold for a batch of n_pairs pairs with total_s1 + total_s2 sequence bytes, and
+ * the host-side expansion of one pair's record into those strings (t1_out / t2_out: `moves` bytes each).
+ */
+uint64_t bioalign_ops_capacity(uint64_t n_pairs, uint64_t total_s1, uint64_t total_s2);
+int bioalign_expand_ops(const uint8_t *s1, uint64_t n, const uint8_t *s2, uint64_t m, const uint8_t *record,
+                        uint64_t moves, uint8_t gap_symbol, uint8_t *t1_out, uint8_t *t2_out);
 
 /*
  * FASTA text -> the batch format, on the GPU (the step before the DP path; ReadFASTA, fasta.go:55-84).

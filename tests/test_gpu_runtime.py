@@ -153,3 +153,25 @@ def test_dense_trace_layout():
                 tl = o["tlen"].cpu().numpy()
                 assert np.array_equal(o["toff"].cpu().numpy(), np.concatenate([[0], np.cumsum(tl)[:-1]]))
         assert got[0] == got[_native.DENSE_TRACES] == _traces(res), mode
+
+
+@pytest.mark.parametrize("mode", ["global", "local", "fitting", "overlap"])
+def test_compact_trace_records(mode):
+    # BIOALIGN_TRACE_OPS: end cell + 2-bit moves per pair; expanded on the host they are the
+    # reference's two strings.  Ragged batch with empty sequences; the records lie back to back in pair order.
+    s1, o1, s2, o2 = _ragged(2500, 41)
+    table, c1, c2 = synth.dna_table(1, -1)
+    eng = _native.Engine([0])
+    ref = _traces(_batch(mode, s1, o1, s2, o2, eng=eng))
+    pb = _native.PackedBatch(s1, o1, s2, o2, mode, table, c1, c2, 1, 1, flags=_native.TRACE_OPS)
+    sc, t1, _, toff, tlen = eng.batch(pb)
+    assert np.all(toff % 4 == 0)
+    sizes = 8 + 4 * ((tlen + 15) // 16)
+    assert np.array_equal(toff, np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64))
+    for p in range(2500):
+        x, y = s1[int(o1[p]):int(o1[p + 1])].tobytes(), s2[int(o2[p]):int(o2[p + 1])].tobytes()
+        a, b = _native.expand_ops(x, y, t1, int(toff[p]), int(tlen[p]))
+        assert (int(sc[p]), a, b) == ref[p], (mode, p)
+    # affine gaps have no move records
+    with pytest.raises(_native.BioAlignError):
+        eng.batch(_native.PackedBatch(s1, o1, s2, o2, mode, table, c1, c2, 3, 1, flags=_native.TRACE_OPS))
