@@ -13,12 +13,13 @@ ap.add_argument("--pairs", type=int, default=1_000_000)
 ap.add_argument("--len", type=int, default=150)
 ap.add_argument("--mode", default="global")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--ops", action="store_true", help="compact trace records (BIOALIGN_TRACE_OPS) instead of the two strings")
 args = ap.parse_args()
 N, L = args.pairs, args.len
 s1, o1, s2, o2 = synth.dna_pairs(N, L, L, config=2)
 table, c1, c2 = synth.dna_table(1, -1)
 eng = _native.Engine([0])
-pb = _native.PackedBatch(s1, o1, s2, o2, args.mode, table, c1, c2, 1, 1)
+pb = _native.PackedBatch(s1, o1, s2, o2, args.mode, table, c1, c2, 1, 1, flags=_native.TRACE_OPS if args.ops else 0)
 best = None
 first = None
 times = []
@@ -35,6 +36,6 @@ for r in range(args.reps):
 scores, t1, t2, toff, tlen = out
 best = best if best is not None else first
 cells = N * L * L
-print(json.dumps({"workload": f"{N} pairs x {L} bp, {args.mode}, bioalign_batch host to host", "ms": round(best * 1e3, 2), "all_ms": times, "first_call_ms_fresh_buffers": round(first * 1e3, 2),
+print(json.dumps({"workload": f"{N} pairs x {L} bp, {args.mode}, bioalign_batch host to host" + (", compact trace records" if args.ops else ""), "ms": round(best * 1e3, 2), "all_ms": times, "first_call_ms_fresh_buffers": round(first * 1e3, 2),
                   "gcups_end_to_end": round(cells / best / 1e9, 1), "bytes_in": int(s1.size + s2.size),
-                  "bytes_out": int(2 * tlen.sum() + 8 * 3 * N), "score_checksum": int(scores.sum())}))
+                  "bytes_out": int((8 * N + 4 * ((tlen + 15) // 16).sum() if args.ops else 2 * tlen.sum()) + 8 * 3 * N), "score_checksum": int(scores.sum())}))
