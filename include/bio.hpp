@@ -257,4 +257,49 @@ inline std::tuple<double, Seq, Seq> AlignGlobalAffine(const Seq &s1, const Seq &
     return {(double)r.score, r.t1, r.t2};
 }
 
+
+// ---- fasta.go -------------------------------------------------------------------------------------------------
+struct FASTASeq {  // fasta.go:17-20
+    std::string Header;  // complete header line, including '>'
+    Seq seq;             // sequence, all lines concatenated (the reference embeds Seq)
+    std::string ID() const
+    {  // fasta.go:23-33
+        if (Header.empty()) return "";
+        const std::string id = Header.substr(1);
+        const size_t sp = id.find(' ');
+        return sp == std::string::npos ? id : id.substr(0, sp);
+    }
+    std::string Desc() const
+    {  // fasta.go:36-45
+        if (Header.empty()) return "";
+        const std::string id = Header.substr(1);
+        const size_t sp = id.find(' ');
+        return sp == std::string::npos ? "" : id.substr(sp + 1);
+    }
+};
+
+// ReadFASTA (fasta.go:55-84) over the GPU parser.  The reference returns the error "No header" for data before the
+// first header line: here a bio::Error whose what() is that text.
+inline std::vector<FASTASeq> ReadFASTA(const std::string &text)
+{
+    bioalign_ctx *ctx = detail::engine();
+    bioalign_fasta *fa = bioalign_fasta_parse(ctx, 0, reinterpret_cast<const uint8_t *>(text.data()), text.size(), 0);
+    if (!fa) throw Error(BIOALIGN_EINVAL, bioalign_last_error(ctx));
+    const uint64_t n = bioalign_fasta_count(fa);
+    std::string raw(bioalign_fasta_bytes(fa), '\0');
+    const int rc = bioalign_fasta_copy_seq(fa, reinterpret_cast<uint8_t *>(&raw[0]));
+    std::vector<FASTASeq> out(n);
+    if (rc == 0) {
+        const uint64_t *off = bioalign_fasta_off(fa), *hb = bioalign_fasta_header_begin(fa), *hl = bioalign_fasta_header_len(fa);
+        for (uint64_t k = 0; k < n; ++k) {
+            out[k].Header = text.substr(hb[k], hl[k]);
+            out[k].seq = raw.substr(off[k], off[k + 1] - off[k]);
+        }
+    }
+    const std::string msg = rc ? bioalign_last_error(ctx) : "";
+    bioalign_fasta_destroy(fa);
+    if (rc) throw Error(rc, msg);
+    return out;
+}
+
 }  // namespace bio

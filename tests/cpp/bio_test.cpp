@@ -104,6 +104,19 @@ static void gpu_tests()
     y.erase(300, 5);
     bio::MatchAligner dna(1, -1);
     CHECK(bio::AlignPairLong("global", x, y, dna, 1) == bio::AlignPair("global", x, y, dna, 1), "long mode = batch mode");
+
+    // ReadFASTA: the reference's example (fasta_test.go:10-44) and its documented behaviour (fasta.go:47-54)
+    {
+        const auto recs = bio::ReadFASTA(">db|123|abc example sequence\nAGACCA\nTACCA");
+        CHECK(recs.size() == 1 && recs[0].Header == ">db|123|abc example sequence" && recs[0].seq == "AGACCATACCA", "ReadFASTA example");
+        CHECK(recs[0].ID() == "db|123|abc" && recs[0].Desc() == "example sequence", "FASTASeq ID / Desc");
+        const auto r2 = bio::ReadFASTA("\n  >a x \r\nAC GT \r\n\r\n>b\n>c\n  TT\n");
+        CHECK(r2.size() == 3 && r2[0].Header == ">a x" && r2[0].seq == "AC GT" && r2[1].seq.empty() && r2[2].seq == "TT", "ReadFASTA trimming, crlf, empty record");
+        CHECK(bio::ReadFASTA("").empty(), "ReadFASTA of nothing");
+        bool no_header = false;
+        try { bio::ReadFASTA("ACGT\n>a\n"); } catch (const bio::Error &e) { no_header = std::string(e.what()).find("No header") != std::string::npos; }
+        CHECK(no_header, "ReadFASTA: data before the first header is the error \"No header\" (fasta.go:72-73)");
+    }
 }
 
 int main(int argc, char **argv)
