@@ -1562,11 +1562,30 @@ extern "C" hipError_t ba_launch_fasta_starts(const BaFastaParams &P, hipStream_t
 extern "C" hipError_t ba_launch_fasta_lines_a(const BaFastaParams &P, hipStream_t st);
 extern "C" hipError_t ba_launch_fasta_lines_b(const BaFastaParams &P, hipStream_t st);
 
+// device memory from the context's pool (DevPool), given back when the object goes
+struct PoolBuf {
+    std::shared_ptr<DevPool> pool;
+    void *p = nullptr;
+    ~PoolBuf()
+    {
+        if (pool) pool->put(p);
+    }
+    int alloc(bioalign_ctx *ctx, int hip_dev, size_t bytes)
+    {
+        pool = ctx->pool;
+        p = pool->get(hip_dev, bytes ? bytes : 16);
+        if (!p) return ctx->fail(BIOALIGN_ENOMEM, "hipMalloc of %zu bytes failed", bytes);
+        return 0;
+    }
+    template <class T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
 struct bioalign_fasta {
     bioalign_ctx *ctx = nullptr;
     int dev = 0;
     uint64_t n_records = 0, total = 0, n_lines = 0;
-    DevBuf seq, off;  // device: the records' data back to back, [n_records + 1] offsets
+    PoolBuf seq, off;  // device: the records' data back to back, [n_records + 1] offsets
     std::vector<uint64_t> h_off, h_hdr_begin, h_hdr_len;
     float kernel_ms = 0.f;
 };
@@ -1589,14 +1608,15 @@ int fasta_parse(bioalign_fasta &F, const uint8_t *text, uint64_t len, bool on_de
     FA_TRY(hipSetDevice(ctx->devices[F.dev]));
     const uint64_t n_chunks = std::max<uint64_t>((len + CHUNK - 1) / CHUNK, 1);
     if (n_chunks > 0x7fffffffull) return ctx->fail(BIOALIGN_EUNSUPPORTED, "FASTA text of %llu bytes is too long for one call", (unsigned long long)len);
-    DevBuf d_text, d_cnt;
+    const int hip_dev = ctx->devices[F.dev];
+    PoolBuf d_text, d_cnt;  // (the context's pool: a pipeline parses file after file)
     int rc;
-    if ((rc = d_cnt.alloc(ctx, n_chunks * 8 + 16))) return rc;
+    if ((rc = d_cnt.alloc(ctx, hip_dev, n_chunks * 8 + 16))) return rc;
     uint64_t *const d_tot = d_cnt.as<uint64_t>() + n_chunks;
     hipStream_t st = nullptr;
     const uint8_t *dtext = text;  // text already in HBM: parsed where it lies
     if (!on_device) {
-        if ((rc = d_text.alloc(ctx, len + 16))) return rc;
+        if ((rc = d_text.alloc(ctx, hip_dev, len + 16))) return rc;
         if (len) FA_TRY(hipMemcpyAsync(d_text.p, text, len, hipMemcpyHostToDevice, st));
         dtext = d_text.as<uint8_t>();
     }
@@ -1632,8 +1652,8 @@ int fasta_parse(bioalign_fasta &F, const uint8_t *text, uint64_t len, bool on_de
     const uint64_t o_ls = 0, o_tb = o_ls + up(n_lines * 8), o_ld = o_tb + up(n_lines * 8), o_lh = o_ld + up(n_lines * 8),
                    o_pd = o_lh + up(n_lines * 8), o_ph = o_pd + up(n_lb * 8), o_tl = o_ph + up(n_lb * 8),
                    ws_bytes = o_tl + up(n_lines * 4);
-    DevBuf d_ws;
-    if ((rc = d_ws.alloc(ctx, ws_bytes))) return rc;
+    PoolBuf d_ws;
+    if ((rc = d_ws.alloc(ctx, hip_dev, ws_bytes))) return rc;
     uint8_t *const ws = d_ws.as<uint8_t>();
     P.line_start = reinterpret_cast<uint64_t *>(ws + o_ls);
     P.n_lines = n_lines;
@@ -1653,9 +1673,9 @@ int fasta_parse(bioalign_fasta &F, const uint8_t *text, uint64_t len, bool on_de
     F.total = tot[0];
     F.n_records = tot[1];
 
-    DevBuf d_tmp;  // header spans + the error word
-    if ((rc = F.seq.alloc(ctx, F.total + 16)) || (rc = F.off.alloc(ctx, (F.n_records + 1) * 8)) ||
-        (rc = d_tmp.alloc(ctx, F.n_records * 16 + 16)))
+    PoolBuf d_tmp;  // header spans + the error word
+    if ((rc = F.seq.alloc(ctx, hip_dev, F.total + 16)) || (rc = F.off.alloc(ctx, hip_dev, (F.n_records + 1) * 8)) ||
+        (rc = d_tmp.alloc(ctx, hip_dev, F.n_records * 16 + 16)))
         return rc;
     uint64_t *const d_hb = d_tmp.as<uint64_t>(), *const d_hl = d_hb + F.n_records;
     uint32_t *const d_err = reinterpret_cast<uint32_t *>(d_hl + F.n_records);

@@ -173,21 +173,45 @@ __global__ void __launch_bounds__(256) fa_starts_kernel(BaFastaParams P)
     }
 }
 
-// one thread per line: trimmed span and kind; ldata[l] = bytes the line adds to its record, lhdr[l] = 1 for a header
+// four lines per thread (their loads in flight together: the kernel waits on memory, not on arithmetic): trimmed
+// span and kind; ldata[l] = bytes the line adds to its record, lhdr[l] = 1 for a header
+#define FA_CLASSIFY_LINES 4
 __global__ void __launch_bounds__(256) fa_classify_kernel(BaFastaParams P)
 {
-    const uint64_t l = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (l >= P.n_lines) return;
-    uint64_t b = P.line_start[l];
-    uint64_t t = (l + 1 < P.n_lines) ? P.line_start[l + 1] - 1 : P.len;  // the newline itself is not part of the line
-    while (b < t && fa_is_space(P.text[b])) ++b;
-    while (t > b && fa_is_space(P.text[t - 1])) --t;
-    const bool blank = (t == b);
-    const bool header = !blank && P.text[b] == '>';
-    P.trim_begin[l] = b;
-    P.ldata[l] = (blank || header) ? 0 : t - b;
-    P.lhdr[l] = header ? 1 : 0;
-    P.trim_len[l] = (uint32_t)(t - b) | (header ? 0x80000000u : 0u);  // (a line is shorter than 2 GB)
+    const uint64_t l0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x);
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint64_t b[FA_CLASSIFY_LINES], t[FA_CLASSIFY_LINES];
+    bool live[FA_CLASSIFY_LINES];
+#pragma unroll
+    for (int q = 0; q < FA_CLASSIFY_LINES; ++q) {
+        const uint64_t l = l0 + q * stride;
+        live[q] = l < P.n_lines;
+        const uint64_t lc = live[q] ? l : 0;
+        b[q] = P.line_start[lc];
+        t[q] = (lc + 1 < P.n_lines) ? P.line_start[lc + 1] - 1 : P.len;  // the newline itself is not part of the line
+    }
+    uint8_t first[FA_CLASSIFY_LINES], last[FA_CLASSIFY_LINES];
+#pragma unroll
+    for (int q = 0; q < FA_CLASSIFY_LINES; ++q) {  // the common case needs these two bytes only
+        first[q] = b[q] < t[q] ? P.text[b[q]] : (uint8_t)'x';
+        last[q] = b[q] < t[q] ? P.text[t[q] - 1] : (uint8_t)'x';
+    }
+#pragma unroll
+    for (int q = 0; q < FA_CLASSIFY_LINES; ++q) {
+        if (!live[q]) continue;
+        const uint64_t l = l0 + q * stride;
+        uint64_t bb = b[q], tt = t[q];
+        if (fa_is_space(first[q]))
+            while (bb < tt && fa_is_space(P.text[bb])) ++bb;
+        if (fa_is_space(last[q]))
+            while (tt > bb && fa_is_space(P.text[tt - 1])) --tt;
+        const bool blank = (tt == bb);
+        const bool header = !blank && (bb == b[q] ? first[q] : P.text[bb]) == '>';
+        P.trim_begin[l] = bb;
+        P.ldata[l] = (blank || header) ? 0 : tt - bb;
+        P.lhdr[l] = header ? 1 : 0;
+        P.trim_len[l] = (uint32_t)(tt - bb) | (header ? 0x80000000u : 0u);  // (a line is shorter than 2 GB)
+    }
 }
 
 // block sums of (ldata, lhdr) over FA_LINES_PER_BLOCK lines
@@ -358,7 +382,7 @@ extern "C" hipError_t ba_launch_fasta_starts(const BaFastaParams &P, hipStream_t
 // classify, block sums
 extern "C" hipError_t ba_launch_fasta_lines_a(const BaFastaParams &P, hipStream_t st)
 {
-    hipLaunchKernelGGL(fa_classify_kernel, dim3((unsigned)((P.n_lines + 255) / 256)), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(fa_classify_kernel, dim3((unsigned)((P.n_lines + 1023) / 1024)), dim3(256), 0, st, P);  // 4 lines per thread
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fa_partial_kernel, dim3((unsigned)P.n_line_blocks), dim3(256), 0, st, P);
