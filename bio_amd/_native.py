@@ -50,6 +50,8 @@ EXPORTS = (
     "bioalign_fasta_header_begin",
     "bioalign_fasta_header_len",
     "bioalign_fasta_copy_seq",
+    "bioalign_all_pairs",
+    "bioalign_fasta_all_pairs",
     "bioalign_stripe_create",
     "bioalign_stripe_destroy",
     "bioalign_stripe_rows",
@@ -157,6 +159,10 @@ def lib():
             fn.argtypes = [C.c_void_p]
         L.bioalign_fasta_copy_seq.restype = C.c_int
         L.bioalign_fasta_copy_seq.argtypes = [C.c_void_p, C.c_void_p]
+        L.bioalign_all_pairs.restype = C.c_int
+        L.bioalign_all_pairs.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
+        L.bioalign_fasta_all_pairs.restype = C.c_int
+        L.bioalign_fasta_all_pairs.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
         L.bioalign_stripe_create.restype = C.c_void_p
         L.bioalign_stripe_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(Batch), C.c_uint64, C.c_uint64]
         L.bioalign_stripe_destroy.argtypes = [C.c_void_p]
@@ -295,6 +301,19 @@ class Engine:
         if rc != 0:
             self._raise(rc)
         return scores[:n], t1, t2, t_off[:n], t_len[:n]
+
+    def all_pairs(self, pb: PackedBatch, fasta: "Fasta | None" = None) -> np.ndarray:
+        """bioalign_all_pairs: `pb` describes a LIST (its s1 side), or only mode / scores / gaps when the list is
+        the records of `fasta`; -> scores[i*(i-1)/2 + j] of aligning sequence i with sequence j < i."""
+        n = fasta.count if fasta is not None else pb.n_pairs
+        scores = np.zeros(max(n * (n - 1) // 2, 1), dtype=np.int64)
+        if fasta is not None:
+            rc = lib().bioalign_fasta_all_pairs(fasta._h, C.byref(pb.c), scores.ctypes.data)
+        else:
+            rc = lib().bioalign_all_pairs(self._h, C.byref(pb.c), scores.ctypes.data)
+        if rc != 0:
+            self._raise(rc)
+        return scores[:n * (n - 1) // 2]
 
     def plan(self, pb: PackedBatch, device_index: int = 0) -> "Plan":
         return Plan(self, pb, device_index)

@@ -16,6 +16,7 @@
 #include <numeric>
 #include <string>
 #include <chrono>
+#include <cmath>
 #include <thread>
 #include <vector>
 
@@ -1791,4 +1792,186 @@ extern "C" int bioalign_expand_ops(const uint8_t *s1, uint64_t n, const uint8_t 
         }
     }
     return 0;
+}
+
+// ----------------------------------------------------------------------------
+// All pairs of one list: the batched client under DNA8List.DistanceMatrix
+// (dna_list.go:951-969) and StrList.DistanceMatrix (str.go:450-469) when the distance function is an alignment
+// score.  The reference calls f(l[i], l[j]) for every j < i; here those n(n-1)/2 calls are one score-only batch.
+// The list lies in HBM once: a pair's two sequences are addressed by their offsets into it (the kernels read a
+// pair's bytes from s + s_off[p] and take its lengths from the plan), so nothing is replicated per pair.
+// ----------------------------------------------------------------------------
+namespace {
+
+// pair p of the lower triangle, row by row: p = i(i-1)/2 + j, j < i
+void pair_of(uint64_t p, uint64_t *i, uint64_t *j)
+{
+    uint64_t r = (uint64_t)((1.0 + std::sqrt(1.0 + 8.0 * (double)p)) / 2.0);
+    while (r > 1 && r * (r - 1) / 2 > p) --r;
+    while ((r + 1) * r / 2 <= p) ++r;
+    *i = r;
+    *j = p - r * (r - 1) / 2;
+}
+
+// pairs [lo, hi) on one device.  d_list: the list's bytes if they already lie on this device, else null (h_list is
+// copied in).
+int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in, const uint64_t *off,
+                    const uint8_t *h_list, const uint8_t *d_list, int64_t *scores, uint64_t lo, uint64_t hi,
+                    std::string *err)
+{
+    bioalign_ctx local;  // (as run_share: concurrent shares do not race on the error string)
+    local.devices = ctx->devices;
+    local.pool = ctx->pool;
+    if (lo >= hi) return 0;
+    const uint64_t n_seqs = in->n_pairs, total = off[n_seqs];
+    const int hip_dev = ctx->devices[dev_index];
+    const uint64_t CH = std::max<uint64_t>(env_u64("BIOALIGN_ALL_PAIRS_CHUNK", 4ull << 20), 1);
+    hipStream_t st = nullptr;
+    bioalign_plan *pl = nullptr;
+    int rc = 0;
+    PoolBuf list, q1, q2, sc;
+    std::vector<uint64_t> v1, v2, p1, p2;
+#define AP_TRY(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            rc = local.fail(BIOALIGN_EHIP, "%s failed: %s", #call, hipGetErrorString(e_));  \
+            goto done;                                                                      \
+        }                                                                                   \
+    } while (0)
+    AP_TRY(hipSetDevice(hip_dev));
+    AP_TRY(hipStreamCreate(&st));
+    if (!d_list) {
+        if ((rc = list.alloc(&local, hip_dev, total + 16)) != 0) goto done;
+        if (total) AP_TRY(hipMemcpyAsync(list.p, h_list, total, hipMemcpyHostToDevice, st));
+        d_list = list.as<uint8_t>();
+    }
+    {
+        const uint64_t cap = std::min(CH, hi - lo);
+        if ((rc = q1.alloc(&local, hip_dev, (cap + 1) * 8)) != 0 || (rc = q2.alloc(&local, hip_dev, (cap + 1) * 8)) != 0 ||
+            (rc = sc.alloc(&local, hip_dev, cap * 8)) != 0)
+            goto done;
+    }
+    for (uint64_t c0 = lo; c0 < hi; c0 += CH) {
+        const uint64_t N = std::min(CH, hi - c0);
+        // the plan sees lengths only (virtual offsets v); the kernels see where each sequence lies in the list (p)
+        v1.assign(N + 1, 0);
+        v2.assign(N + 1, 0);
+        p1.assign(N + 1, 0);
+        p2.assign(N + 1, 0);
+        uint64_t i, j;
+        pair_of(c0, &i, &j);
+        for (uint64_t k = 0; k < N; ++k) {
+            v1[k + 1] = v1[k] + (off[i + 1] - off[i]);
+            v2[k + 1] = v2[k] + (off[j + 1] - off[j]);
+            p1[k] = off[i];
+            p2[k] = off[j];
+            if (++j == i) {
+                ++i;
+                j = 0;
+            }
+        }
+        bioalign_batch_t sub = *in;
+        sub.s1 = sub.s2 = nullptr;
+        sub.s1_off = v1.data();
+        sub.s2_off = v2.data();
+        sub.n_pairs = N;
+        sub.flags = BIOALIGN_SCORE_ONLY;
+        pl = new bioalign_plan;
+        pl->ctx = &local;
+        pl->device = dev_index;
+        pl->pool = ctx->pool;
+        if (plan_build(pl, &sub) != 0) {
+            rc = local.code ? local.code : BIOALIGN_EINVAL;
+            goto done;
+        }
+        AP_TRY(hipMemcpyAsync(q1.p, p1.data(), (N + 1) * 8, hipMemcpyHostToDevice, st));
+        AP_TRY(hipMemcpyAsync(q2.p, p2.data(), (N + 1) * 8, hipMemcpyHostToDevice, st));
+        rc = bioalign_plan_run(pl, d_list, q1.as<uint64_t>(), d_list, q2.as<uint64_t>(), sc.as<int64_t>(), nullptr,
+                               nullptr, nullptr, nullptr, st);
+        if (rc) goto done;
+        AP_TRY(hipMemcpyAsync(scores + c0, sc.p, N * 8, hipMemcpyDeviceToHost, st));
+        AP_TRY(hipStreamSynchronize(st));
+        bioalign_plan_destroy(pl);
+        pl = nullptr;
+    }
+done:
+    if (st) (void)hipStreamSynchronize(st);
+    if (pl) bioalign_plan_destroy(pl);  // touches pl->ctx (== &local), still alive here
+    if (st) (void)hipStreamDestroy(st);
+    if (rc) *err = local.err;
+    return rc;
+#undef AP_TRY
+}
+
+int all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, const uint64_t *off, const uint8_t *h_list,
+              const uint8_t *d_list, int d_list_dev, int64_t *scores)
+{
+    const uint64_t n = in->n_pairs;
+    if (n < 2) return 0;
+    if (n > (1ull << 31)) return ctx->fail(BIOALIGN_EINVAL, "too many sequences");
+    for (uint64_t k = 0; k < n; ++k)
+        if (off[k + 1] < off[k]) return ctx->fail(BIOALIGN_EINVAL, "offsets must be non-decreasing (sequence %llu)", (unsigned long long)k);
+    const uint64_t P = n * (n - 1) / 2;
+    // ranges of pairs balanced by cell count, one per device (as bioalign_batch); a list that already lies on one
+    // device stays there
+    const int D = d_list ? 1 : (int)ctx->devices.size();
+    std::vector<uint64_t> cut(D + 1, P);
+    cut[0] = 0;
+    if (D > 1) {
+        // row i costs (len_i + 1) * sum over j < i of (len_j + 1)
+        std::vector<double> cum(n + 1, 0.0), rowpre(n + 1, 0.0);
+        for (uint64_t k = 0; k < n; ++k) cum[k + 1] = cum[k] + (double)(off[k + 1] - off[k] + 1);
+        for (uint64_t k = 0; k < n; ++k) rowpre[k + 1] = rowpre[k] + (double)(off[k + 1] - off[k] + 1) * cum[k];
+        for (int d = 1; d < D; ++d) {
+            const double target = rowpre[n] * d / D;
+            uint64_t i = (uint64_t)(std::upper_bound(rowpre.begin(), rowpre.end(), target) - rowpre.begin());
+            i = std::min<uint64_t>(std::max<uint64_t>(i, 1), n) - 1;  // rowpre[i] <= target
+            uint64_t j = 0;
+            if (i >= 1) {
+                const double rem = (target - rowpre[i]) / (double)(off[i + 1] - off[i] + 1);
+                j = (uint64_t)(std::lower_bound(cum.begin(), cum.begin() + i + 1, rem) - cum.begin());
+                j = std::min(j, i);
+            }
+            cut[d] = std::min(std::max(i * (i > 0 ? i - 1 : 0) / 2 + j, cut[d - 1]), P);
+        }
+    }
+    std::vector<int> rcs(D, 0);
+    std::vector<std::string> errs(D);
+    if (D == 1) {
+        rcs[0] = all_pairs_share(ctx, d_list ? d_list_dev : 0, in, off, h_list, d_list, scores, 0, P, &errs[0]);
+    } else {
+        std::vector<std::thread> th;
+        for (int d = 0; d < D; ++d)
+            th.emplace_back([&, d] { rcs[d] = all_pairs_share(ctx, d, in, off, h_list, nullptr, scores, cut[d], cut[d + 1], &errs[d]); });
+        for (auto &t : th) t.join();
+    }
+    for (int d = 0; d < D; ++d)
+        if (rcs[d]) {
+            ctx->err = errs[d];
+            return rcs[d];
+        }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int bioalign_all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, int64_t *scores)
+{
+    if (!ctx) return BIOALIGN_EINVAL;
+    if (!in || !in->s1_off) return ctx->fail(BIOALIGN_EINVAL, "null argument");
+    if (in->n_pairs >= 2 && !scores) return ctx->fail(BIOALIGN_EINVAL, "null scores buffer");
+    if (in->s1_off[in->n_pairs] && !in->s1) return ctx->fail(BIOALIGN_EINVAL, "null sequence bytes");
+    return all_pairs(ctx, in, in->s1_off, in->s1, nullptr, 0, scores);
+}
+
+extern "C" int bioalign_fasta_all_pairs(const bioalign_fasta *F, const bioalign_batch_t *in, int64_t *scores)
+{
+    if (!F) return BIOALIGN_EINVAL;
+    bioalign_ctx *ctx = F->ctx;
+    if (!in) return ctx->fail(BIOALIGN_EINVAL, "null argument");
+    if (F->n_records >= 2 && !scores) return ctx->fail(BIOALIGN_EINVAL, "null scores buffer");
+    bioalign_batch_t sub = *in;
+    sub.n_pairs = F->n_records;
+    return all_pairs(ctx, &sub, F->h_off.data(), nullptr, F->seq.as<uint8_t>(), F->dev, scores);
 }

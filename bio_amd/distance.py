@@ -1,0 +1,72 @@
+"""All-pairs distance matrices over alignment scores.
+
+The reference's DNA8List.DistanceMatrix (dna_list.go:951-969) and StrList.DistanceMatrix (str.go:450-469) call a
+distance function f(l[i], l[j]) for every j < i and mirror the value into a full [][]float64 with a zero
+diagonal.  When f is a function of an alignment score -- an AlignDist -- the n(n-1)/2 alignments are one
+score-only batch on the GPU (bioalign_all_pairs): the list lies in HBM once and pairs address it by offset.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native
+from .subst_matrix import score_table
+
+
+class AlignDist:
+    """A DistFunc8 / DistFuncStr (dna_list.go:951, str.go:450) of the form to_dist(score of AlignPair(mode, a, b,
+    aligner, gap)), or of the Gotoh score when gapExtend differs from gapOpen.  to_dist maps an int64 array of
+    scores to float64 distances (default: -score, so that a higher score is a smaller distance)."""
+
+    def __init__(self, mode: str, a, gapOpen: int, gapExtend: int | None = None, to_dist=None):
+        if mode not in _native.MODES:
+            raise KeyError(mode)
+        self.mode, self.a = mode, a
+        self.gap_open = int(gapOpen)
+        self.gap_extend = self.gap_open if gapExtend is None else int(gapExtend)
+        self.to_dist = to_dist or (lambda s: -s.astype(np.float64))
+
+    def __call__(self, s: bytes, t: bytes) -> float:
+        """One pair, as the reference would call it."""
+        from .align import _run_batch
+
+        scores, _, _ = _run_batch(self.mode, [bytes(s)], [bytes(t)], self.a, self.gap_open, self.gap_extend, score_only=True)
+        return float(self.to_dist(np.asarray(scores, dtype=np.int64))[0])
+
+
+def AlignScores(l, f: AlignDist, engine=None) -> np.ndarray:
+    """scores[i*(i-1)/2 + j] = score of aligning l[i] (rows) with l[j] (columns), j < i.
+    `l`: a list of bytes, or a FastaBatch (records already in HBM)."""
+    from .align import _gap, engine as default_engine, pack_sequences
+    from .fasta import FastaBatch
+
+    eng = engine or default_engine()
+    if isinstance(l, FastaBatch):
+        syms = np.unique(l._fa.seq_bytes()).tolist()
+        data, off = np.zeros(0, np.uint8), np.zeros(1, np.uint64)
+    else:
+        data, off = pack_sequences([bytes(s) for s in l])
+        syms = np.unique(data).tolist()
+    table, code1, code2 = score_table(f.a, syms, syms)
+    pb = _native.PackedBatch(data, off, np.zeros(0, np.uint8), off, f.mode, table, code1, code2, f.gap_open, f.gap_extend,
+                             gap_symbol=_gap(), flags=_native.SCORE_ONLY)
+    return eng.all_pairs(pb, fasta=l._fa if isinstance(l, FastaBatch) else None)
+
+
+def DistanceMatrix(l, f) -> list:
+    """dna_list.go:955-969 / str.go:454-469: d[i][j] = d[j][i] = f(l[i], l[j]) for j < i, zero diagonal, as a list
+    of lists of floats.  An empty list panics in the reference (d[0] of an empty slice): IndexError here.
+    f: an AlignDist (batched on the GPU), or any callable (called pair by pair, as the reference does)."""
+    n = l.count if hasattr(l, "count") and not isinstance(l, (list, tuple)) else len(l)
+    if n == 0:
+        raise IndexError("index out of range [0] with length 0")
+    d = np.zeros((n, n), dtype=np.float64)
+    if n > 1:
+        ii, jj = np.tril_indices(n, -1)  # row by row: pair i(i-1)/2 + j
+        if isinstance(f, AlignDist):
+            v = np.asarray(f.to_dist(AlignScores(l, f)), dtype=np.float64)
+        else:
+            v = np.array([f(l[i], l[j]) for i, j in zip(ii.tolist(), jj.tolist())], dtype=np.float64)
+        d[ii, jj] = v
+        d[jj, ii] = v
+    return d.tolist()

@@ -259,6 +259,31 @@ const uint64_t *bioalign_fasta_header_len(const bioalign_fasta *fasta);
 int bioalign_fasta_copy_seq(const bioalign_fasta *fasta, uint8_t *dst); /* all sequence bytes to host memory */
 
 /*
+ * All pairs of one list.  The batched client under
+ * DNA8List.DistanceMatrix (dna_list.go:951-969) and StrList.DistanceMatrix
+ * (str.go:450-469) for distance functions that are a function of an alignment
+ * score: the reference calls f(l[i], l[j]) for every j < i, one alignment per
+ * call; here those n(n-1)/2 alignments are one score-only batch.
+ *
+ * `in` describes the LIST, not pairs: n_pairs = number of sequences n, s1 / s1_off
+ * = their bytes back to back and n+1 offsets (host memory); s2 / s2_off are
+ * ignored.  Sequence i is the row sequence (code1, table row) and sequence j the
+ * column sequence (code2) of pair (i, j), as in f(l[i], l[j]).  mode, score table,
+ * gap penalties as in bioalign_batch; flags are ignored (scores only).
+ *
+ * scores[i*(i-1)/2 + j] (j < i; n(n-1)/2 values, host memory) = the score of that
+ * alignment.  The list is copied to each device once; pairs address it by offset,
+ * nothing is replicated per pair.  Pairs are split over the context's devices by
+ * cell count, no collective.  n < 2: nothing is written.
+ *
+ * bioalign_fasta_all_pairs: the same over the records of a parsed FASTA text,
+ * which already lie in HBM (on the parse's device; in->n_pairs, s1, s1_off are
+ * ignored too).
+ */
+int bioalign_all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, int64_t *scores);
+int bioalign_fasta_all_pairs(const bioalign_fasta *fasta, const bioalign_batch_t *in, int64_t *scores);
+
+/*
  * Timing hooks for the benchmark (no counterpart in the reference): the plan
  * records a pair of HIP events around every DP kernel launch, on the launch
  * stream, into a fixed pool of 256 pairs.  Once the stream has been

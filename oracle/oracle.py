@@ -280,3 +280,22 @@ def ReadFASTA(text: bytes):
         raise ValueError("No header")
     raw = bytes(seq)
     return [(text[hb[i]:hb[i] + hl[i]], raw[off[i]:off[i + 1]]) for i in range(k)]
+
+
+def DistanceMatrix(l, f):
+    """dna_list.go:955-969 (= str.go:454-469), statement by statement: d[0] is made first (an empty list
+    panics there), then every row i >= 1 calls f(l[i], l[j]) for j < i and mirrors the value."""
+    n = len(l)
+    if n == 0:
+        raise GoPanic("index out of range [0] with length 0")
+    d = [None] * n
+    d[0] = [0.0] * n
+    for i in range(1, n):
+        li = l[i]
+        di = [0.0] * n
+        d[i] = di
+        for j, lj in enumerate(l[:i]):
+            dij = float(f(li, lj))
+            di[j] = dij
+            d[j][i] = dij
+    return d
