@@ -1813,11 +1813,16 @@ void pair_of(uint64_t p, uint64_t *i, uint64_t *j)
     *j = p - r * (r - 1) / 2;
 }
 
-// pairs [lo, hi) on one device.  d_list: the list's bytes if they already lie on this device, else null (h_list is
-// copied in).
+extern "C" hipError_t ba_launch_pair_offsets(const uint64_t *off, uint64_t c0, uint64_t n, uint64_t *q1, uint64_t *q2,
+                                             hipStream_t st);
+
+// Pairs [lo, hi) on one device, in chunks of at most BIOALIGN_ALL_PAIRS_CHUNK pairs (one plan each).
+// d_list / d_off: the list's bytes and offsets if they already lie on this device, else null (h_list and off are
+// copied in).  The plan sees lengths only (virtual offsets); where each pair's sequences lie in the list is
+// computed on the device (ba_pair_offsets_kernel).
 int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in, const uint64_t *off,
-                    const uint8_t *h_list, const uint8_t *d_list, int64_t *scores, uint64_t lo, uint64_t hi,
-                    std::string *err)
+                    const uint8_t *h_list, const uint8_t *d_list, const uint64_t *d_off, int64_t *scores, uint64_t lo,
+                    uint64_t hi, std::string *err)
 {
     bioalign_ctx local;  // (as run_share: concurrent shares do not race on the error string)
     local.devices = ctx->devices;
@@ -1829,8 +1834,16 @@ int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in
     hipStream_t st = nullptr;
     bioalign_plan *pl = nullptr;
     int rc = 0;
-    PoolBuf list, q1, q2, sc;
-    std::vector<uint64_t> v1, v2, p1, p2;
+    PoolBuf list, loff, q1, q2, sc;
+    std::vector<uint64_t> v1, v2;
+    const bool timing = env_u64("BIOALIGN_TIMING", 0) != 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(now() - t).count();
+    };
+    const auto t_start = now();
+    auto t_mark = t_start;
+    double t_fill = 0, t_plan = 0, t_run = 0;
 #define AP_TRY(call)                                                                        \
     do {                                                                                    \
         hipError_t e_ = (call);                                                             \
@@ -1842,35 +1855,37 @@ int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in
     AP_TRY(hipSetDevice(hip_dev));
     AP_TRY(hipStreamCreate(&st));
     if (!d_list) {
-        if ((rc = list.alloc(&local, hip_dev, total + 16)) != 0) goto done;
+        if ((rc = list.alloc(&local, hip_dev, total + 16)) != 0 || (rc = loff.alloc(&local, hip_dev, (n_seqs + 1) * 8)) != 0)
+            goto done;
         if (total) AP_TRY(hipMemcpyAsync(list.p, h_list, total, hipMemcpyHostToDevice, st));
+        AP_TRY(hipMemcpyAsync(loff.p, off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
         d_list = list.as<uint8_t>();
+        d_off = loff.as<uint64_t>();
     }
     {
         const uint64_t cap = std::min(CH, hi - lo);
         if ((rc = q1.alloc(&local, hip_dev, (cap + 1) * 8)) != 0 || (rc = q2.alloc(&local, hip_dev, (cap + 1) * 8)) != 0 ||
             (rc = sc.alloc(&local, hip_dev, cap * 8)) != 0)
             goto done;
+        v1.resize(cap + 1);
+        v2.resize(cap + 1);
     }
     for (uint64_t c0 = lo; c0 < hi; c0 += CH) {
         const uint64_t N = std::min(CH, hi - c0);
-        // the plan sees lengths only (virtual offsets v); the kernels see where each sequence lies in the list (p)
-        v1.assign(N + 1, 0);
-        v2.assign(N + 1, 0);
-        p1.assign(N + 1, 0);
-        p2.assign(N + 1, 0);
+        AP_TRY(ba_launch_pair_offsets(d_off, c0, N, q1.as<uint64_t>(), q2.as<uint64_t>(), st));
         uint64_t i, j;
         pair_of(c0, &i, &j);
+        v1[0] = v2[0] = 0;
         for (uint64_t k = 0; k < N; ++k) {
             v1[k + 1] = v1[k] + (off[i + 1] - off[i]);
             v2[k + 1] = v2[k] + (off[j + 1] - off[j]);
-            p1[k] = off[i];
-            p2[k] = off[j];
             if (++j == i) {
                 ++i;
                 j = 0;
             }
         }
+        t_fill += ms_since(t_mark);
+        t_mark = now();
         bioalign_batch_t sub = *in;
         sub.s1 = sub.s2 = nullptr;
         sub.s1_off = v1.data();
@@ -1885,8 +1900,8 @@ int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in
             rc = local.code ? local.code : BIOALIGN_EINVAL;
             goto done;
         }
-        AP_TRY(hipMemcpyAsync(q1.p, p1.data(), (N + 1) * 8, hipMemcpyHostToDevice, st));
-        AP_TRY(hipMemcpyAsync(q2.p, p2.data(), (N + 1) * 8, hipMemcpyHostToDevice, st));
+        t_plan += ms_since(t_mark);
+        t_mark = now();
         rc = bioalign_plan_run(pl, d_list, q1.as<uint64_t>(), d_list, q2.as<uint64_t>(), sc.as<int64_t>(), nullptr,
                                nullptr, nullptr, nullptr, st);
         if (rc) goto done;
@@ -1894,7 +1909,12 @@ int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in
         AP_TRY(hipStreamSynchronize(st));
         bioalign_plan_destroy(pl);
         pl = nullptr;
+        t_run += ms_since(t_mark);
+        t_mark = now();
     }
+    if (timing)
+        fprintf(stderr, "bioalign all-pairs dev %d, %llu pairs: lengths %.2f ms, plan %.2f, kernels + copy out %.2f, total %.2f\n",
+                dev_index, (unsigned long long)(hi - lo), t_fill, t_plan, t_run, ms_since(t_start));
 done:
     if (st) (void)hipStreamSynchronize(st);
     if (pl) bioalign_plan_destroy(pl);  // touches pl->ctx (== &local), still alive here
@@ -1905,7 +1925,7 @@ done:
 }
 
 int all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, const uint64_t *off, const uint8_t *h_list,
-              const uint8_t *d_list, int d_list_dev, int64_t *scores)
+              const uint8_t *d_list, const uint64_t *d_off, int d_list_dev, int64_t *scores)
 {
     const uint64_t n = in->n_pairs;
     if (n < 2) return 0;
@@ -1913,9 +1933,13 @@ int all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, const uint64_t *off
     for (uint64_t k = 0; k < n; ++k)
         if (off[k + 1] < off[k]) return ctx->fail(BIOALIGN_EINVAL, "offsets must be non-decreasing (sequence %llu)", (unsigned long long)k);
     const uint64_t P = n * (n - 1) / 2;
-    // ranges of pairs balanced by cell count, one per device (as bioalign_batch); a list that already lies on one
-    // device stays there
-    const int D = d_list ? 1 : (int)ctx->devices.size();
+    // Ranges of pairs balanced by cell count: one per device (as bioalign_batch; a list that already lies on one
+    // device stays there), and for large lists several per device, each driven by a host thread of its own, so
+    // that the host work of one range (lengths, plan) overlaps the kernels of another.  BIOALIGN_HOST_SHARES
+    // sets the ranges per device.
+    const int ndev = d_list ? 1 : (int)ctx->devices.size();
+    const int per_dev = (int)std::min<uint64_t>(std::max<uint64_t>(env_u64("BIOALIGN_HOST_SHARES", P >= 262144 ? 3 : 1), 1), 8);
+    const int D = ndev * per_dev;
     std::vector<uint64_t> cut(D + 1, P);
     cut[0] = 0;
     if (D > 1) {
@@ -1938,12 +1962,15 @@ int all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, const uint64_t *off
     }
     std::vector<int> rcs(D, 0);
     std::vector<std::string> errs(D);
+    auto share = [&](int d) {
+        rcs[d] = all_pairs_share(ctx, d_list ? d_list_dev : d / per_dev, in, off, h_list, d_list, d_off, scores, cut[d],
+                                 cut[d + 1], &errs[d]);
+    };
     if (D == 1) {
-        rcs[0] = all_pairs_share(ctx, d_list ? d_list_dev : 0, in, off, h_list, d_list, scores, 0, P, &errs[0]);
+        share(0);
     } else {
         std::vector<std::thread> th;
-        for (int d = 0; d < D; ++d)
-            th.emplace_back([&, d] { rcs[d] = all_pairs_share(ctx, d, in, off, h_list, nullptr, scores, cut[d], cut[d + 1], &errs[d]); });
+        for (int d = 0; d < D; ++d) th.emplace_back(share, d);
         for (auto &t : th) t.join();
     }
     for (int d = 0; d < D; ++d)
@@ -1962,7 +1989,7 @@ extern "C" int bioalign_all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in,
     if (!in || !in->s1_off) return ctx->fail(BIOALIGN_EINVAL, "null argument");
     if (in->n_pairs >= 2 && !scores) return ctx->fail(BIOALIGN_EINVAL, "null scores buffer");
     if (in->s1_off[in->n_pairs] && !in->s1) return ctx->fail(BIOALIGN_EINVAL, "null sequence bytes");
-    return all_pairs(ctx, in, in->s1_off, in->s1, nullptr, 0, scores);
+    return all_pairs(ctx, in, in->s1_off, in->s1, nullptr, nullptr, 0, scores);
 }
 
 extern "C" int bioalign_fasta_all_pairs(const bioalign_fasta *F, const bioalign_batch_t *in, int64_t *scores)
@@ -1973,5 +2000,5 @@ extern "C" int bioalign_fasta_all_pairs(const bioalign_fasta *F, const bioalign_
     if (F->n_records >= 2 && !scores) return ctx->fail(BIOALIGN_EINVAL, "null scores buffer");
     bioalign_batch_t sub = *in;
     sub.n_pairs = F->n_records;
-    return all_pairs(ctx, &sub, F->h_off.data(), nullptr, F->seq.as<uint8_t>(), F->dev, scores);
+    return all_pairs(ctx, &sub, F->h_off.data(), nullptr, F->seq.as<uint8_t>(), F->off.as<uint64_t>(), F->dev, scores);
 }
