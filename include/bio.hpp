@@ -19,6 +19,7 @@
 //   + AlignPairBatch, AlignAffineBatch, AlignPairLong (additive)
 #pragma once
 #include <array>
+#include <functional>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -300,6 +301,80 @@ inline std::vector<FASTASeq> ReadFASTA(const std::string &text)
     bioalign_fasta_destroy(fa);
     if (rc) throw Error(rc, msg);
     return out;
+}
+
+// ---- DistanceMatrix (dna_list.go:951-969, str.go:450-469) ----------------------------------------------------
+// The reference takes any func(a, b) float64 and calls it for every j < i.  AlignDist is the distance function
+// that is a function of an alignment score: its n(n-1)/2 alignments are ONE score-only batch on the GPU
+// (bioalign_all_pairs); the list lies in HBM once.  toDist maps a score to the distance (default: -score).
+struct AlignDist {
+    std::string mode;
+    const Aligner *a;
+    int gapOpen, gapExtend;
+    std::function<double(long long)> toDist;
+    AlignDist(std::string mode_, const Aligner &a_, int gapOpen_, int gapExtend_ = -1,
+              std::function<double(long long)> toDist_ = [](long long s) { return (double)-s; })
+        : mode(std::move(mode_)), a(&a_), gapOpen(gapOpen_), gapExtend(gapExtend_ < 0 ? gapOpen_ : gapExtend_),
+          toDist(std::move(toDist_))
+    {
+    }
+};
+
+inline std::vector<std::vector<double>> DistanceMatrix(const std::vector<Seq> &l, const AlignDist &f)
+{
+    if (l.empty()) throw std::out_of_range("index out of range [0] with length 0");  // d[0] of an empty slice
+    const size_t n = l.size();
+    std::vector<std::vector<double>> d(n, std::vector<double>(n, 0.0));
+    const int m = detail::mode_of(f.mode);
+    if (m < 0) throw std::invalid_argument("unknown mode " + f.mode);
+    if (n < 2) return d;
+    std::vector<uint64_t> off(n + 1, 0);
+    std::string c;
+    std::array<bool, 256> seen{};
+    for (size_t k = 0; k < n; ++k) {
+        c += l[k];
+        off[k + 1] = c.size();
+        for (unsigned char b : l[k]) seen[b] = true;
+    }
+    std::array<uint8_t, 256> code{};
+    std::vector<uint8_t> syms;
+    for (int b = 0; b < 256; ++b)
+        if (seen[b]) code[b] = (uint8_t)syms.size(), syms.push_back((uint8_t)b);
+    const int na = syms.empty() ? 1 : (int)syms.size();
+    std::vector<int32_t> table((size_t)na * na, 0);
+    for (size_t i = 0; i < syms.size(); ++i)
+        for (size_t j = 0; j < syms.size(); ++j) table[i * na + j] = f.a->Score(syms[i], syms[j]);
+    c.push_back(0);
+    bioalign_batch_t in{};
+    in.s1 = (const uint8_t *)c.data();
+    in.s1_off = off.data();
+    in.n_pairs = n;
+    in.mode = m;
+    in.score_table = table.data();
+    in.na = in.nb = na;
+    in.code1 = in.code2 = code.data();
+    in.gap_open = f.gapOpen;
+    in.gap_extend = f.gapExtend;
+    in.gap_symbol = GapSymbol;
+    in.flags = BIOALIGN_SCORE_ONLY;
+    std::vector<int64_t> sc(n * (n - 1) / 2);
+    bioalign_ctx *ctx = detail::engine();
+    const int rc = bioalign_all_pairs(ctx, &in, sc.data());
+    if (rc != 0) throw Error(rc, bioalign_last_error(ctx));
+    for (size_t i = 1; i < n; ++i)
+        for (size_t j = 0; j < i; ++j) d[i][j] = d[j][i] = f.toDist(sc[i * (i - 1) / 2 + j]);
+    return d;
+}
+// any other distance function: the reference's loop as it stands (host code calling the caller's f)
+template <class F>
+inline std::vector<std::vector<double>> DistanceMatrix(const std::vector<Seq> &l, F f)
+{
+    if (l.empty()) throw std::out_of_range("index out of range [0] with length 0");
+    const size_t n = l.size();
+    std::vector<std::vector<double>> d(n, std::vector<double>(n, 0.0));
+    for (size_t i = 1; i < n; ++i)
+        for (size_t j = 0; j < i; ++j) d[i][j] = d[j][i] = f(l[i], l[j]);
+    return d;
 }
 
 }  // namespace bio

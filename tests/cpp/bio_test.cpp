@@ -117,6 +117,25 @@ static void gpu_tests()
         try { bio::ReadFASTA("ACGT\n>a\n"); } catch (const bio::Error &e) { no_header = std::string(e.what()).find("No header") != std::string::npos; }
         CHECK(no_header, "ReadFASTA: data before the first header is the error \"No header\" (fasta.go:72-73)");
     }
+
+    // DistanceMatrix: the reference's example (dna_list_test.go:320-337 = str_test.go:218-235), Hamming distances.
+    // Equal lengths, match 0 / mismatch -1 and 2 * gap >= length: -(global score) is the Hamming distance.
+    {
+        const std::vector<bio::Seq> l = {"TTTCCATTTA", "GATTCATTTC", "TTTCCATTTT", "GTTCCATTTA"};
+        const std::vector<std::vector<double>> want = {{0, 4, 1, 1}, {4, 0, 4, 3}, {1, 4, 0, 2}, {1, 3, 2, 0}};
+        bio::MatchAligner ham(0, -1);
+        CHECK(bio::DistanceMatrix(l, bio::AlignDist("global", ham, 5)) == want, "DistanceMatrix example through the engine");
+        auto hamming = [](const bio::Seq &a, const bio::Seq &b) {
+            double d = 0;
+            for (size_t k = 0; k < a.size() && k < b.size(); ++k) d += a[k] != b[k];
+            return d;
+        };
+        CHECK(bio::DistanceMatrix(l, hamming) == want, "DistanceMatrix example, caller's function");
+        bool threw = false;
+        try { bio::DistanceMatrix(std::vector<bio::Seq>{}, bio::AlignDist("global", ham, 5)); } catch (const std::out_of_range &) { threw = true; }
+        CHECK(threw, "DistanceMatrix of an empty list panics (dna_list.go:957)");
+        CHECK(bio::DistanceMatrix({"ACGT"}, bio::AlignDist("local", ham, 5)) == std::vector<std::vector<double>>{{0}}, "one sequence");
+    }
 }
 
 int main(int argc, char **argv)
