@@ -14,4 +14,4 @@ GapSymbol = ord("-")  # package variable (align.go:3); assign bio_amd.GapSymbol 
 
 Seq = bytes  # seq.go:18
 from .fasta import FASTASeq, FastaBatch, ReadFASTA, ReadFASTAFile  # noqa: F401,E402
-from .distance import AlignDist, AlignScores, DistanceMatrix  # noqa: F401,E402
+from .distance import AlignDist, AlignScores, AlignScoresSharded, DistanceMatrix, pair_ranges  # noqa: F401,E402

@@ -51,6 +51,7 @@ EXPORTS = (
     "bioalign_fasta_header_len",
     "bioalign_fasta_copy_seq",
     "bioalign_all_pairs",
+    "bioalign_all_pairs_range",
     "bioalign_fasta_all_pairs",
     "bioalign_stripe_create",
     "bioalign_stripe_destroy",
@@ -161,6 +162,8 @@ def lib():
         L.bioalign_fasta_copy_seq.argtypes = [C.c_void_p, C.c_void_p]
         L.bioalign_all_pairs.restype = C.c_int
         L.bioalign_all_pairs.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
+        L.bioalign_all_pairs_range.restype = C.c_int
+        L.bioalign_all_pairs_range.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_uint64, C.c_uint64, C.c_void_p]
         L.bioalign_fasta_all_pairs.restype = C.c_int
         L.bioalign_fasta_all_pairs.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
         L.bioalign_stripe_create.restype = C.c_void_p
@@ -302,18 +305,23 @@ class Engine:
             self._raise(rc)
         return scores[:n], t1, t2, t_off[:n], t_len[:n]
 
-    def all_pairs(self, pb: PackedBatch, fasta: "Fasta | None" = None) -> np.ndarray:
+    def all_pairs(self, pb: PackedBatch, fasta: "Fasta | None" = None, pair_range=None) -> np.ndarray:
         """bioalign_all_pairs: `pb` describes a LIST (its s1 side), or only mode / scores / gaps when the list is
-        the records of `fasta`; -> scores[i*(i-1)/2 + j] of aligning sequence i with sequence j < i."""
+        the records of `fasta`; -> scores[i*(i-1)/2 + j] of aligning sequence i with sequence j < i.
+        pair_range=(first, end): only those pairs of that numbering (bioalign_all_pairs_range)."""
         n = fasta.count if fasta is not None else pb.n_pairs
-        scores = np.zeros(max(n * (n - 1) // 2, 1), dtype=np.int64)
+        total = n * (n - 1) // 2
+        first, end = (0, total) if pair_range is None else (int(pair_range[0]), int(pair_range[1]))
+        scores = np.zeros(max(end - first, 1), dtype=np.int64)
         if fasta is not None:
+            if pair_range is not None:
+                raise ValueError("pair ranges are for host lists")
             rc = lib().bioalign_fasta_all_pairs(fasta._h, C.byref(pb.c), scores.ctypes.data)
         else:
-            rc = lib().bioalign_all_pairs(self._h, C.byref(pb.c), scores.ctypes.data)
+            rc = lib().bioalign_all_pairs_range(self._h, C.byref(pb.c), first, end - first, scores.ctypes.data)
         if rc != 0:
             self._raise(rc)
-        return scores[:n * (n - 1) // 2]
+        return scores[:end - first]
 
     def plan(self, pb: PackedBatch, device_index: int = 0) -> "Plan":
         return Plan(self, pb, device_index)

@@ -1824,6 +1824,7 @@ int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in
                     const uint8_t *h_list, const uint8_t *d_list, const uint64_t *d_off, int64_t *scores, uint64_t lo,
                     uint64_t hi, std::string *err)
 {
+    // (scores: where pair 0's score would lie; the caller has rebased it for a range that starts elsewhere)
     bioalign_ctx local;  // (as run_share: concurrent shares do not race on the error string)
     local.devices = ctx->devices;
     local.pool = ctx->pool;
@@ -1924,25 +1925,33 @@ done:
 #undef AP_TRY
 }
 
+// pairs [first, first + count) of the triangle; scores[0] is pair `first`
 int all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, const uint64_t *off, const uint8_t *h_list,
-              const uint8_t *d_list, const uint64_t *d_off, int d_list_dev, int64_t *scores)
+              const uint8_t *d_list, const uint64_t *d_off, int d_list_dev, uint64_t first, uint64_t count,
+              int64_t *scores)
 {
     const uint64_t n = in->n_pairs;
-    if (n < 2) return 0;
     if (n > (1ull << 31)) return ctx->fail(BIOALIGN_EINVAL, "too many sequences");
+    const uint64_t P = n < 2 ? 0 : n * (n - 1) / 2;
+    if (count == ~0ull) count = P - std::min(first, P);
+    if (first > P || count > P - first) return ctx->fail(BIOALIGN_EINVAL, "pair range outside the triangle of %llu pairs", (unsigned long long)P);
+    if (count == 0) return 0;
+    if (!scores) return ctx->fail(BIOALIGN_EINVAL, "null scores buffer");
     for (uint64_t k = 0; k < n; ++k)
         if (off[k + 1] < off[k]) return ctx->fail(BIOALIGN_EINVAL, "offsets must be non-decreasing (sequence %llu)", (unsigned long long)k);
-    const uint64_t P = n * (n - 1) / 2;
+    scores -= first;  // indexed by pair number from here on (never dereferenced outside [first, first + count))
     // Ranges of pairs balanced by cell count: one per device (as bioalign_batch; a list that already lies on one
     // device stays there), and for large lists several per device, each driven by a host thread of its own, so
     // that the host work of one range (lengths, plan) overlaps the kernels of another.  BIOALIGN_HOST_SHARES
     // sets the ranges per device.
     const int ndev = d_list ? 1 : (int)ctx->devices.size();
-    const int per_dev = (int)std::min<uint64_t>(std::max<uint64_t>(env_u64("BIOALIGN_HOST_SHARES", P >= 262144 ? 3 : 1), 1), 8);
+    const int per_dev = (int)std::min<uint64_t>(std::max<uint64_t>(env_u64("BIOALIGN_HOST_SHARES", count >= 262144 ? 3 : 1), 1), 8);
     const int D = ndev * per_dev;
-    std::vector<uint64_t> cut(D + 1, P);
-    cut[0] = 0;
-    if (D > 1) {
+    std::vector<uint64_t> cut(D + 1, first + count);
+    cut[0] = first;
+    if (D > 1 && count != P) {
+        for (int d = 1; d < D; ++d) cut[d] = first + count * d / D;  // a caller's range: by pair count
+    } else if (D > 1) {
         // row i costs (len_i + 1) * sum over j < i of (len_j + 1)
         std::vector<double> cum(n + 1, 0.0), rowpre(n + 1, 0.0);
         for (uint64_t k = 0; k < n; ++k) cum[k + 1] = cum[k] + (double)(off[k + 1] - off[k] + 1);
@@ -1983,13 +1992,18 @@ int all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, const uint64_t *off
 
 }  // namespace
 
-extern "C" int bioalign_all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, int64_t *scores)
+extern "C" int bioalign_all_pairs_range(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t first_pair,
+                                        uint64_t n_range, int64_t *scores)
 {
     if (!ctx) return BIOALIGN_EINVAL;
     if (!in || !in->s1_off) return ctx->fail(BIOALIGN_EINVAL, "null argument");
-    if (in->n_pairs >= 2 && !scores) return ctx->fail(BIOALIGN_EINVAL, "null scores buffer");
     if (in->s1_off[in->n_pairs] && !in->s1) return ctx->fail(BIOALIGN_EINVAL, "null sequence bytes");
-    return all_pairs(ctx, in, in->s1_off, in->s1, nullptr, nullptr, 0, scores);
+    return all_pairs(ctx, in, in->s1_off, in->s1, nullptr, nullptr, 0, first_pair, n_range, scores);
+}
+
+extern "C" int bioalign_all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, int64_t *scores)
+{
+    return bioalign_all_pairs_range(ctx, in, 0, ~0ull, scores);
 }
 
 extern "C" int bioalign_fasta_all_pairs(const bioalign_fasta *F, const bioalign_batch_t *in, int64_t *scores)
@@ -1997,8 +2011,7 @@ extern "C" int bioalign_fasta_all_pairs(const bioalign_fasta *F, const bioalign_
     if (!F) return BIOALIGN_EINVAL;
     bioalign_ctx *ctx = F->ctx;
     if (!in) return ctx->fail(BIOALIGN_EINVAL, "null argument");
-    if (F->n_records >= 2 && !scores) return ctx->fail(BIOALIGN_EINVAL, "null scores buffer");
     bioalign_batch_t sub = *in;
     sub.n_pairs = F->n_records;
-    return all_pairs(ctx, &sub, F->h_off.data(), nullptr, F->seq.as<uint8_t>(), F->off.as<uint64_t>(), F->dev, scores);
+    return all_pairs(ctx, &sub, F->h_off.data(), nullptr, F->seq.as<uint8_t>(), F->off.as<uint64_t>(), F->dev, 0, ~0ull, scores);
 }

@@ -34,9 +34,9 @@ class AlignDist:
         return float(self.to_dist(np.asarray(scores, dtype=np.int64))[0])
 
 
-def AlignScores(l, f: AlignDist, engine=None) -> np.ndarray:
+def AlignScores(l, f: AlignDist, engine=None, pair_range=None) -> np.ndarray:
     """scores[i*(i-1)/2 + j] = score of aligning l[i] (rows) with l[j] (columns), j < i.
-    `l`: a list of bytes, or a FastaBatch (records already in HBM)."""
+    `l`: a list of bytes, or a FastaBatch (records already in HBM).  pair_range=(first, end): only those pairs."""
     from .align import _gap, engine as default_engine, pack_sequences
     from .fasta import FastaBatch
 
@@ -50,7 +50,66 @@ def AlignScores(l, f: AlignDist, engine=None) -> np.ndarray:
     table, code1, code2 = score_table(f.a, syms, syms)
     pb = _native.PackedBatch(data, off, np.zeros(0, np.uint8), off, f.mode, table, code1, code2, f.gap_open, f.gap_extend,
                              gap_symbol=_gap(), flags=_native.SCORE_ONLY)
-    return eng.all_pairs(pb, fasta=l._fa if isinstance(l, FastaBatch) else None)
+    return eng.all_pairs(pb, fasta=l._fa if isinstance(l, FastaBatch) else None, pair_range=pair_range)
+
+
+def pair_ranges(lens, world: int):
+    """Cuts the n(n-1)/2 pairs (numbered i(i-1)/2 + j, j < i) into `world` contiguous ranges of nearly equal cell
+    count, as bioalign_all_pairs does across the devices of one context: row i costs (len_i + 1) times the sum of
+    (len_j + 1) over j < i.  -> bounds[world + 1], bounds[0] = 0, bounds[world] = n(n-1)/2, non-decreasing."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    w = np.asarray(lens, dtype=np.float64) + 1.0
+    n = w.size
+    total = n * (n - 1) // 2
+    bounds = np.zeros(world + 1, dtype=np.int64)
+    bounds[world] = total
+    if n >= 2:
+        cum = np.concatenate(([0.0], np.cumsum(w)))          # cum[i] = sum over j < i
+        rowpre = np.concatenate(([0.0], np.cumsum(w * cum[:-1])))
+        for r in range(1, world):
+            target = rowpre[n] * r / world
+            i = min(max(int(np.searchsorted(rowpre, target, side="right")), 1), n) - 1
+            j = 0
+            if i >= 1:
+                j = min(int(np.searchsorted(cum[:i + 1], (target - rowpre[i]) / w[i], side="left")), i)
+            bounds[r] = min(i * (i - 1) // 2 + j if i > 0 else 0, total)
+    np.maximum.accumulate(bounds, out=bounds)
+    return bounds
+
+
+def AlignScoresSharded(l, f: AlignDist, *, group=None, scores_fn=None) -> np.ndarray:
+    """AlignScores across the ranks of a torch.distributed process group (one process per GPU):
+    every rank calls this with the same list, aligns range `rank` of pair_ranges() on its own GPU
+    (bioalign_all_pairs_range) and all ranks return the whole score vector.  Pairs are independent: the only
+    traffic is the gather of the scores themselves (8 bytes per pair), after the kernels.
+
+    scores_fn(l, f, first, end) -> int64 scores of pairs [first, end): the default is the GPU; there is no CPU
+    fallback (the CPU test injects the oracle explicitly)."""
+    import torch
+    import torch.distributed as dist
+
+    if scores_fn is None:
+        def scores_fn(l, f, first, end):
+            return AlignScores(l, f, pair_range=(first, end))
+
+    l = [bytes(s) for s in l]
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    bounds = pair_ranges([len(s) for s in l], world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    mine = np.asarray(scores_fn(l, f, lo, hi), dtype=np.int64) if hi > lo else np.zeros(0, np.int64)
+    if world == 1:
+        return mine
+    # equal-sized all_gather (ranges differ in pair count: pad to the longest)
+    xdev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    longest = int(np.max(np.diff(bounds)))
+    buf = torch.zeros(max(longest, 1), dtype=torch.int64)
+    buf[:hi - lo] = torch.from_numpy(mine)
+    buf = buf.to(xdev)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    return np.concatenate([parts[r].cpu().numpy()[:int(bounds[r + 1] - bounds[r])] for r in range(world)])
 
 
 def DistanceMatrix(l, f) -> list:

@@ -281,6 +281,10 @@ int bioalign_fasta_copy_seq(const bioalign_fasta *fasta, uint8_t *dst); /* all s
  * ignored too).
  */
 int bioalign_all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, int64_t *scores);
+/* Pairs [first_pair, first_pair + n_range) of the same numbering only; scores[0] is pair first_pair.  For programs
+ * that run one process per GPU and give every rank a range of the triangle (bio_amd/distance.py). */
+int bioalign_all_pairs_range(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t first_pair, uint64_t n_range,
+                             int64_t *scores);
 int bioalign_fasta_all_pairs(const bioalign_fasta *fasta, const bioalign_batch_t *in, int64_t *scores);
 
 /*
