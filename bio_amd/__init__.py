@@ -13,5 +13,5 @@ from . import _native  # noqa: F401
 GapSymbol = ord("-")  # package variable (align.go:3); assign bio_amd.GapSymbol to change it
 
 Seq = bytes  # seq.go:18
-from .fasta import FASTASeq, FastaBatch, ReadFASTA, ReadFASTAFile  # noqa: F401,E402
+from .fasta import FASTAReader, FASTASeq, FastaBatch, NewFASTAReader, ReadFASTA, ReadFASTAFile  # noqa: F401,E402
 from .distance import AlignDist, AlignScores, AlignScoresSharded, DistanceMatrix, pair_ranges  # noqa: F401,E402

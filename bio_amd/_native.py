@@ -40,6 +40,8 @@ EXPORTS = (
     "bioalign_ops_capacity",
     "bioalign_expand_ops",
     "bioalign_fasta_parse",
+    "bioalign_fasta_parse_reader",
+    "bioalign_fasta_too_long_at",
     "bioalign_fasta_destroy",
     "bioalign_fasta_count",
     "bioalign_fasta_bytes",
@@ -148,6 +150,10 @@ def lib():
                                           C.c_void_p, C.c_void_p]
         L.bioalign_fasta_parse.restype = C.c_void_p
         L.bioalign_fasta_parse.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int]
+        L.bioalign_fasta_parse_reader.restype = C.c_void_p
+        L.bioalign_fasta_parse_reader.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64]
+        L.bioalign_fasta_too_long_at.restype = C.c_int64
+        L.bioalign_fasta_too_long_at.argtypes = [C.c_void_p]
         L.bioalign_fasta_destroy.argtypes = [C.c_void_p]
         for fn in (L.bioalign_fasta_count, L.bioalign_fasta_bytes):
             fn.restype = C.c_uint64
@@ -438,7 +444,9 @@ class Fasta:
     """Owns a bioalign_fasta: FASTA text parsed on the GPU into the batch format (include/bioalign.h).
     `text` is bytes / a uint8 array on the host, or a raw device address (int) with length `length`."""
 
-    def __init__(self, engine: Engine, text, length: int | None = None, device_index: int = 0):
+    def __init__(self, engine: Engine, text, length: int | None = None, device_index: int = 0, reader_line_limit=None):
+        """reader_line_limit: None = ReadFASTA's rules; an int = FASTAReader.ReadSeq's rules with a bufio buffer of
+        that many bytes (0: bufio's default), bioalign_fasta_parse_reader."""
         self.engine = engine
         if isinstance(text, int):
             ptr, n, on_dev = text, int(length), 1
@@ -447,11 +455,15 @@ class Fasta:
             arr = np.frombuffer(bytes(text), dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, dtype=np.uint8)
             self._keep = arr
             ptr, n, on_dev = (arr.ctypes.data if arr.size else None), int(arr.size), 0
-        h = lib().bioalign_fasta_parse(engine._h, device_index, ptr, n, on_dev)
+        if reader_line_limit is None:
+            h = lib().bioalign_fasta_parse(engine._h, device_index, ptr, n, on_dev)
+        else:
+            h = lib().bioalign_fasta_parse_reader(engine._h, device_index, ptr, n, on_dev, int(reader_line_limit))
         if not h:
             engine._raise(EINVAL)
         self._h = C.c_void_p(h)
         L = lib()
+        self.too_long_at = int(L.bioalign_fasta_too_long_at(self._h))
         self.count = int(L.bioalign_fasta_count(self._h))
         self.total_bytes = int(L.bioalign_fasta_bytes(self._h))
         self.kernel_ms = float(L.bioalign_fasta_kernel_ms(self._h))

@@ -1589,6 +1589,7 @@ struct bioalign_fasta {
     PoolBuf seq, off;  // device: the records' data back to back, [n_records + 1] offsets
     std::vector<uint64_t> h_off, h_hdr_begin, h_hdr_len;
     float kernel_ms = 0.f;
+    int64_t too_long_at = -1;  // reader rules: the ReadSeq call (0-based) that meets a line too long for the buffer
 };
 
 namespace {
@@ -1602,7 +1603,8 @@ namespace {
         }                                                                                              \
     } while (0)
 
-int fasta_parse(bioalign_fasta &F, const uint8_t *text, uint64_t len, bool on_device)
+// line_limit == 0: ReadFASTA's rules; else FASTAReader.ReadSeq's with a bufio buffer of that many bytes
+int fasta_parse(bioalign_fasta &F, const uint8_t *text, uint64_t len, bool on_device, uint64_t line_limit)
 {
     bioalign_ctx *ctx = F.ctx;
     const uint64_t CHUNK = 16384, LPB = 2048;
@@ -1612,8 +1614,9 @@ int fasta_parse(bioalign_fasta &F, const uint8_t *text, uint64_t len, bool on_de
     const int hip_dev = ctx->devices[F.dev];
     PoolBuf d_text, d_cnt;  // (the context's pool: a pipeline parses file after file)
     int rc;
-    if ((rc = d_cnt.alloc(ctx, hip_dev, n_chunks * 8 + 16))) return rc;
+    if ((rc = d_cnt.alloc(ctx, hip_dev, n_chunks * 8 + 32))) return rc;
     uint64_t *const d_tot = d_cnt.as<uint64_t>() + n_chunks;
+    unsigned long long *const d_long = reinterpret_cast<unsigned long long *>(d_tot + 2);
     hipStream_t st = nullptr;
     const uint8_t *dtext = text;  // text already in HBM: parsed where it lies
     if (!on_device) {
@@ -1639,6 +1642,10 @@ int fasta_parse(bioalign_fasta &F, const uint8_t *text, uint64_t len, bool on_de
     P.len = len;
     P.n_chunks = n_chunks;
     P.chunk_count = d_cnt.as<uint64_t>();
+    P.reader = line_limit != 0;
+    P.line_limit = line_limit;
+    P.too_long = d_long;
+    FA_TRY(hipMemsetAsync(d_long, 0xff, 8, st));
     FA_TRY(ba_launch_fasta_count(P, st));
     FA_TRY(ba_launch_fasta_scan1(P.chunk_count, nullptr, n_chunks, d_tot, st));
     uint64_t tot[2] = {0, 0};
@@ -1699,9 +1706,18 @@ int fasta_parse(bioalign_fasta &F, const uint8_t *text, uint64_t len, bool on_de
         FA_TRY(hipMemcpyAsync(F.h_hdr_begin.data(), d_hb, F.n_records * 8, hipMemcpyDeviceToHost, st));
         FA_TRY(hipMemcpyAsync(F.h_hdr_len.data(), d_hl, F.n_records * 8, hipMemcpyDeviceToHost, st));
     }
+    unsigned long long too_long = ~0ull;
+    if (P.reader) FA_TRY(hipMemcpyAsync(&too_long, d_long, 8, hipMemcpyDeviceToHost, st));
     FA_TRY(hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&F.kernel_ms, e0, e1);
     if (err) return ctx->fail(BIOALIGN_EINVAL, "No header");  // the reference's error text (fasta.go:73)
+    if (too_long != ~0ull) {
+        // the call that is reading record h - 1 meets the line (h headers before it; also when the line is itself
+        // a header: it is read by the call that looks for the end of the record before); no header yet: the first
+        uint64_t h = 0;
+        FA_TRY(hipMemcpy(&h, P.lhdr + too_long, 8, hipMemcpyDeviceToHost));
+        F.too_long_at = h ? (int64_t)h - 1 : 0;
+    }
     return 0;
 }
 
@@ -1722,12 +1738,35 @@ extern "C" bioalign_fasta *bioalign_fasta_parse(bioalign_ctx *ctx, int device_in
     bioalign_fasta *F = new bioalign_fasta;
     F->ctx = ctx;
     F->dev = device_index;
-    if (fasta_parse(*F, text, len, text_on_device != 0) != 0) {
+    if (fasta_parse(*F, text, len, text_on_device != 0, 0) != 0) {
         delete F;
         return nullptr;
     }
     return F;
 }
+
+extern "C" bioalign_fasta *bioalign_fasta_parse_reader(bioalign_ctx *ctx, int device_index, const uint8_t *text,
+                                                       uint64_t len, int text_on_device, uint64_t line_limit)
+{
+    if (!ctx) return nullptr;
+    if (device_index < 0 || device_index >= (int)ctx->devices.size()) {
+        ctx->fail(BIOALIGN_EINVAL, "device index %d out of range", device_index);
+        return nullptr;
+    }
+    if (!text && len) {
+        ctx->fail(BIOALIGN_EINVAL, "null text");
+        return nullptr;
+    }
+    bioalign_fasta *F = new bioalign_fasta;
+    F->ctx = ctx;
+    F->dev = device_index;
+    if (fasta_parse(*F, text, len, text_on_device != 0, line_limit ? line_limit : 4096) != 0) {
+        delete F;
+        return nullptr;
+    }
+    return F;
+}
+extern "C" int64_t bioalign_fasta_too_long_at(const bioalign_fasta *F) { return F ? F->too_long_at : -1; }
 
 extern "C" void bioalign_fasta_destroy(bioalign_fasta *F)
 {

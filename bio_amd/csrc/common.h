@@ -149,4 +149,10 @@ struct BaFastaParams {
     uint64_t *off;            // out: [n_records + 1]
     uint64_t *hdr_begin, *hdr_len;   // out: [n_records] header lines as spans of the text
     uint32_t *error;          // out: != 0: data before the first header
+    // FASTAReader.ReadSeq's rules instead of ReadFASTA's (fasta.go:109-142): lines end at "\n" or "\r\n" and are
+    // otherwise taken as they are (no trimming), data before the first header is ignored, and a line that does not
+    // fit bufio's buffer of `line_limit` bytes (terminator included) is the error "FASTA line too long"
+    int reader;
+    uint64_t line_limit;
+    unsigned long long *too_long;  // out: the first such line (min over lines), ~0 if none
 };

@@ -201,10 +201,19 @@ __global__ void __launch_bounds__(256) fa_classify_kernel(BaFastaParams P)
         if (!live[q]) continue;
         const uint64_t l = l0 + q * stride;
         uint64_t bb = b[q], tt = t[q];
-        if (fa_is_space(first[q]))
-            while (bb < tt && fa_is_space(P.text[bb])) ++bb;
-        if (fa_is_space(last[q]))
-            while (tt > bb && fa_is_space(P.text[tt - 1])) --tt;
+        if (P.reader) {
+            // bufio.Reader.ReadLine (fasta.go:117): "\n" or "\r\n" ends a line and is dropped, nothing else is;
+            // the last line may lack its terminator, and then keeps a trailing "\r"
+            const bool terminated = l + 1 < P.n_lines;
+            const uint64_t raw = tt - bb + (terminated ? 1 : 0);
+            if (terminated ? raw > P.line_limit : raw >= P.line_limit) atomicMin(P.too_long, (unsigned long long)l);
+            if (terminated && tt > bb && last[q] == '\r') --tt;
+        } else {
+            if (fa_is_space(first[q]))
+                while (bb < tt && fa_is_space(P.text[bb])) ++bb;
+            if (fa_is_space(last[q]))
+                while (tt > bb && fa_is_space(P.text[tt - 1])) --tt;
+        }
         const bool blank = (tt == bb);
         const bool header = !blank && (bb == b[q] ? first[q] : P.text[bb]) == '>';
         P.trim_begin[l] = bb;
@@ -332,7 +341,7 @@ __global__ void __launch_bounds__(256) fa_emit_kernel(BaFastaParams P)
                 }
                 tl[q] = 0;
             } else if (tl[q] != 0 && rec[q] == 0) {  // data before the first header (fasta.go:72-73)
-                if (sub == 0) atomicOr(P.error, 1u);
+                if (sub == 0 && !P.reader) atomicOr(P.error, 1u);  // (ReadSeq ignores it, fasta.go:137-138)
                 tl[q] = 0;
             }
             src[q] = P.text + beg[q];

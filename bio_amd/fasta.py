@@ -39,18 +39,19 @@ class FastaBatch:
     """The parsed records, resident on the device: .count, .off (host offsets), .d_seq / .d_off (device
     addresses), .headers (host strings), .kernel_ms."""
 
-    def __init__(self, text, engine=None):
+    def __init__(self, text, engine=None, reader_line_limit=None):
         from .align import engine as default_engine
 
         self.text = bytes(text)
-        self._fa = _native.Fasta(engine or default_engine(), self.text)
+        self._fa = _native.Fasta(engine or default_engine(), self.text, reader_line_limit=reader_line_limit)
+        self.too_long_at = self._fa.too_long_at
         self.count, self.off = self._fa.count, self._fa.off
         self.d_seq, self.d_off, self.kernel_ms = self._fa.d_seq, self._fa.d_off, self._fa.kernel_ms
         self.headers = [self.text[int(b):int(b + l)].decode("latin-1")
                         for b, l in zip(self._fa.header_begin, self._fa.header_len)]
 
     def sequences(self):
-        raw = self._fa.seq_bytes().tobytes()
+        raw = self._fa.seq_bytes().tobytes()  # (reader rules: ignored leading data leaves off[0] unused bytes in front)
         return [raw[int(self.off[k]):int(self.off[k + 1])] for k in range(self.count)]
 
 
@@ -73,3 +74,35 @@ def ReadFASTAFile(path: str) -> list:
     """fasta.go:88-95"""
     with open(path, "rb") as f:
         return ReadFASTA(f)
+
+
+class FASTAReader:
+    """fasta.go:93-142: the reference's second reader, one record per ReadSeq call.  Its rules differ from
+    ReadFASTA's (no trimming, "\\r\\n" handled by bufio.ReadLine, data before the first header ignored, lines
+    beyond bufio's 4096-byte buffer are an error).  Here the whole stream is parsed on the GPU at construction
+    (bioalign_fasta_parse_reader) and ReadSeq hands the records out one by one: EOFError stands for io.EOF,
+    ValueError("FASTA line too long") for that error -- after which the reader stays in error (the reference
+    would go on from the middle of the line)."""
+
+    def __init__(self, data, line_limit: int = 0):
+        if hasattr(data, "read"):
+            data = data.read()
+        if isinstance(data, str):
+            data = data.encode()
+        self._fb = FastaBatch(data, reader_line_limit=line_limit)
+        self._raw = self._fb._fa.seq_bytes().tobytes()
+        self._next = 0
+
+    def ReadSeq(self) -> FASTASeq:
+        k, fb = self._next, self._fb
+        if fb.too_long_at >= 0 and k >= fb.too_long_at:
+            raise ValueError("FASTA line too long")  # fasta.go:125
+        if k >= fb.count:
+            raise EOFError("EOF")  # io.EOF, fasta.go:120-123
+        self._next += 1
+        return FASTASeq(fb.headers[k], self._raw[int(fb.off[k]):int(fb.off[k + 1])])
+
+
+def NewFASTAReader(r, line_limit: int = 0) -> FASTAReader:
+    """fasta.go:100-102"""
+    return FASTAReader(r, line_limit)

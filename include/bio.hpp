@@ -303,6 +303,50 @@ inline std::vector<FASTASeq> ReadFASTA(const std::string &text)
     return out;
 }
 
+// FASTAReader (fasta.go:93-142), the reference's second reader: one record per ReadSeq call, and rules of its own
+// (bufio.ReadLine: "\n" or "\r\n" ends a line, nothing is trimmed, data before the first header is ignored, a line
+// beyond bufio's 4096-byte buffer is an error).  The stream is parsed on the GPU when the reader is made
+// (bioalign_fasta_parse_reader).  ReadSeq returns the reference's error as text: "" for nil, "EOF" for io.EOF,
+// "FASTA line too long"; after that error the reader stays in error.
+class FASTAReader {
+public:
+    explicit FASTAReader(const std::string &text, uint64_t lineLimit = 0)
+    {
+        bioalign_ctx *ctx = detail::engine();
+        bioalign_fasta *fa = bioalign_fasta_parse_reader(ctx, 0, reinterpret_cast<const uint8_t *>(text.data()), text.size(), 0, lineLimit);
+        if (!fa) throw Error(BIOALIGN_EINVAL, bioalign_last_error(ctx));
+        const uint64_t n = bioalign_fasta_count(fa);
+        std::string raw(bioalign_fasta_bytes(fa), '\0');
+        const int rc = bioalign_fasta_copy_seq(fa, reinterpret_cast<uint8_t *>(&raw[0]));
+        if (rc == 0) {
+            const uint64_t *off = bioalign_fasta_off(fa), *hb = bioalign_fasta_header_begin(fa), *hl = bioalign_fasta_header_len(fa);
+            recs_.resize(n);
+            for (uint64_t k = 0; k < n; ++k) {
+                recs_[k].Header = text.substr(hb[k], hl[k]);
+                recs_[k].seq = raw.substr(off[k], off[k + 1] - off[k]);
+            }
+            tooLongAt_ = bioalign_fasta_too_long_at(fa);
+        }
+        const std::string msg = rc ? bioalign_last_error(ctx) : "";
+        bioalign_fasta_destroy(fa);
+        if (rc) throw Error(rc, msg);
+    }
+    std::string ReadSeq(FASTASeq &out)
+    {  // fasta.go:109-142
+        out = FASTASeq{};
+        if (tooLongAt_ >= 0 && (int64_t)next_ >= tooLongAt_) return "FASTA line too long";
+        if (next_ >= recs_.size()) return "EOF";
+        out = recs_[next_++];
+        return "";
+    }
+
+private:
+    std::vector<FASTASeq> recs_;
+    size_t next_ = 0;
+    int64_t tooLongAt_ = -1;
+};
+inline FASTAReader NewFASTAReader(const std::string &text) { return FASTAReader(text); }  // fasta.go:100-102
+
 // ---- DistanceMatrix (dna_list.go:951-969, str.go:450-469) ----------------------------------------------------
 // The reference takes any func(a, b) float64 and calls it for every j < i.  AlignDist is the distance function
 // that is a function of an alignment score: its n(n-1)/2 alignments are ONE score-only batch on the GPU

@@ -247,6 +247,18 @@ int bioalign_expand_ops(const uint8_t *s1, uint64_t n, const uint8_t *s2, uint64
 typedef struct bioalign_fasta bioalign_fasta;
 bioalign_fasta *bioalign_fasta_parse(bioalign_ctx *ctx, int device_index, const uint8_t *text, uint64_t len,
                                      int text_on_device);
+/*
+ * The same with the rules of the reference's streaming reader, FASTAReader.ReadSeq (fasta.go:93-142), which differ
+ * from ReadFASTA's: a line ends at "\n" or "\r\n" and is otherwise taken as it is (no trimming: a header is a line
+ * whose FIRST byte is '>'), data before the first header is ignored instead of being an error, and a line that does
+ * not fit bufio.Reader's buffer (line_limit bytes, terminator included; 0 = bufio's default 4096) is the error
+ * "FASTA line too long".  The whole stream is parsed in one call; record k is what the (k+1)-th ReadSeq call
+ * returns.  bioalign_fasta_too_long_at: -1, or the 0-based ReadSeq call that returns that error (records before it
+ * are good, those from it on are not meaningful).
+ */
+bioalign_fasta *bioalign_fasta_parse_reader(bioalign_ctx *ctx, int device_index, const uint8_t *text, uint64_t len,
+                                            int text_on_device, uint64_t line_limit);
+int64_t bioalign_fasta_too_long_at(const bioalign_fasta *fasta);
 void bioalign_fasta_destroy(bioalign_fasta *fasta);
 uint64_t bioalign_fasta_count(const bioalign_fasta *fasta);           /* records */
 uint64_t bioalign_fasta_bytes(const bioalign_fasta *fasta);           /* sequence bytes of all records */

@@ -299,3 +299,58 @@ def DistanceMatrix(l, f):
             di[j] = dij
             d[j][i] = dij
     return d
+
+
+class FASTAReader:
+    """fasta.go:93-142 restated, with bufio.Reader.ReadLine (Go standard library, bufio.go: ReadLine / ReadSlice)
+    over a buffer of `size` bytes (bufio's default 4096, fasta.go:101).  ReadSeq() -> (header, seq, err) with err
+    None, "EOF" or "FASTA line too long"."""
+
+    def __init__(self, data: bytes, size: int = 4096):
+        self.data, self.pos, self.size = bytes(data), 0, size
+        self.nextHeader = b""
+
+    def _read_line(self):
+        """-> (line, isPrefix, err)"""
+        data, p, B = self.data, self.pos, self.size
+        if p >= len(data):
+            return None, False, "EOF"
+        window = data[p:p + B]
+        k = window.find(b"\n")
+        if k >= 0:  # ReadSlice found the delimiter: drop "\n" or "\r\n"
+            self.pos = p + k + 1
+            line = window[:k + 1]
+            drop = 2 if len(line) > 1 and line[-2] == 13 else 1
+            return line[:-drop], False, None
+        if len(window) == B:  # ErrBufferFull: the start of a line that does not fit
+            if window[-1] == 13:  # "put the '\r' back on buf and drop it from line"
+                self.pos = p + B - 1
+                return window[:-1], True, None
+            self.pos = p + B
+            return window, True, None
+        self.pos = len(data)  # the last line, without a terminator: returned as it is
+        return window, False, None
+
+    def ReadSeq(self):
+        header, seq = self.nextHeader, b""
+        self.nextHeader = b""
+        while True:
+            line, is_pre, err = self._read_line()
+            if err is not None:
+                if err == "EOF" and header > b"":
+                    err = None
+                break
+            if is_pre:
+                err = "FASTA line too long"
+                break
+            if len(line) == 0:
+                continue
+            if line[0] == 62:  # '>'
+                if header > b"":
+                    self.nextHeader = line
+                    break
+                header = line
+            elif header > b"":
+                seq += line
+            # else: initial data without a header is ignored
+        return header, seq, err

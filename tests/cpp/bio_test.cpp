@@ -118,6 +118,19 @@ static void gpu_tests()
         CHECK(no_header, "ReadFASTA: data before the first header is the error \"No header\" (fasta.go:72-73)");
     }
 
+    // FASTAReader.ReadSeq: the reference's example (fasta_test.go:46-64) and the rules that differ from ReadFASTA's
+    {
+        bio::FASTAReader r = bio::NewFASTAReader(">db|123|abc example sequence\nAGACCA\nTACCA");
+        bio::FASTASeq s;
+        CHECK(r.ReadSeq(s).empty() && s.Header == ">db|123|abc example sequence" && s.seq == "AGACCATACCA", "ReadSeq example");
+        CHECK(r.ReadSeq(s) == "EOF", "ReadSeq: EOF after the last record");
+        bio::FASTAReader r2("junk\n>a x \r\n AC GT \r\n\r\n>b\n");
+        CHECK(r2.ReadSeq(s).empty() && s.Header == ">a x " && s.seq == " AC GT ", "ReadSeq: nothing trimmed, crlf, leading data ignored");
+        CHECK(r2.ReadSeq(s).empty() && s.Header == ">b" && s.seq.empty() && r2.ReadSeq(s) == "EOF", "ReadSeq: empty last record");
+        bio::FASTAReader r3(">a\nAC\n>b\n" + std::string(4096, 'A') + "\n>c\nC\n");
+        CHECK(r3.ReadSeq(s).empty() && s.seq == "AC" && r3.ReadSeq(s) == "FASTA line too long", "ReadSeq: line beyond bufio's buffer (fasta.go:124-126)");
+    }
+
     // DistanceMatrix: the reference's example (dna_list_test.go:320-337 = str_test.go:218-235), Hamming distances.
     // Equal lengths, match 0 / mismatch -1 and 2 * gap >= length: -(global score) is the Hamming distance.
     {

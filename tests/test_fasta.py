@@ -102,3 +102,85 @@ def test_fasta_to_alignment_without_a_host_copy():
         x, y = s1[int(o1[p]):int(o1[p + 1])].tobytes(), s2[int(o2[p]):int(o2[p + 1])].tobytes()
         a, l = int(toff[p]), int(tlen[p])
         assert (int(sc[p]), t1[a:a + l].tobytes(), t2[a:a + l].tobytes()) == O.AlignPair("fitting", x, y, oa, 1)
+
+
+# ---- the reference's second reader: FASTAReader.ReadSeq (fasta.go:93-142) --------------------------------------
+READER_EXAMPLE = b">db|123|abc example sequence\nAGACCA\nTACCA"  # fasta_test.go:46-64
+
+
+def _oracle_read_all(text, size=4096):
+    r = O.FASTAReader(text, size)
+    out = []
+    while True:
+        h, s, err = r.ReadSeq()
+        if err is not None:
+            return out, err
+        out.append((h, s))
+
+
+def test_oracle_reader_reference_example():
+    r = O.FASTAReader(READER_EXAMPLE)
+    assert r.ReadSeq() == (b">db|123|abc example sequence", b"AGACCATACCA", None)
+    assert r.ReadSeq()[2] == "EOF"
+    # rules that differ from ReadFASTA's: nothing is trimmed, crlf is a line end, leading data is ignored
+    recs, err = _oracle_read_all(b"junk\n\n>a x \r\n AC GT \r\n\r\n >not a header\n>b\n>c\nTT\r")
+    assert err == "EOF"
+    assert recs == [(b">a x ", b" AC GT  >not a header"), (b">b", b""), (b">c", b"TT\r")]
+    assert _oracle_read_all(b"") == ([], "EOF") and _oracle_read_all(b"ACGT\n") == ([], "EOF")
+    # bufio's buffer: 4095 bytes + "\n" fit, 4096 + "\n" do not; the records before the line are good
+    ok = b">a\n" + b"A" * 4095 + b"\n>b\nC\n"
+    assert _oracle_read_all(ok)[1] == "EOF" and len(_oracle_read_all(ok)[0]) == 2
+    bad = b">a\nAC\n>b\n" + b"A" * 4096 + b"\n>c\nC\n"
+    assert _oracle_read_all(bad) == ([(b">a", b"AC")], "FASTA line too long")
+
+
+def _gpu_read_all(text, limit=0):
+    import bio_amd
+
+    r = bio_amd.NewFASTAReader(text, limit)
+    out = []
+    while True:
+        try:
+            f = r.ReadSeq()
+        except EOFError:
+            return out, "EOF"
+        except ValueError as e:
+            return out, str(e)
+        out.append((f.Header.encode("latin-1"), f.Seq))
+
+
+READER_CASES = [
+    READER_EXAMPLE,
+    b"",
+    b"ACGT\n",
+    b"\n\n\n",
+    b">only header",
+    b"junk\n\n>a x \r\n AC GT \r\n\r\n >not a header\n>b\n>c\nTT\r",
+    b">a\r\nAC\r\n\r\nGT\r\n>b\r\n\r\n",
+    b"\r\n>a\nA\rC\n\r",
+    b">a\n" + b"A" * 4095 + b"\n>b\nC\n",
+    b">a\n" + b"A" * 4094 + b"\r\n>b\nC\n",
+    b">a\nAC\n>b\n" + b"A" * 4096 + b"\n>c\nC\n",
+    b">a\nAC\n>b\n" + b"A" * 4095 + b"\r\n>c\nC\n",
+    b"x" * 5000 + b"\n>a\nAC\n",
+    b">a\nAC\n>" + b"h" * 4200 + b"\nGG\n",
+    b">a\nAC\n>b\nGG\n" + b"T" * 4096,
+    b">a\nAC\n>b\nGG\n" + b"T" * 4095,
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(len(READER_CASES)))
+def test_gpu_reader_matches_oracle(k):
+    text = READER_CASES[k]
+    assert _gpu_read_all(text) == _oracle_read_all(text)
+
+
+@pytest.mark.gpu
+def test_gpu_reader_random_and_small_buffer():
+    rng = np.random.default_rng(3)
+    pieces = [b">", b">h d", b"ACGT", b"A C", b" ", b"\r", b"\n", b"\r\n", b"\n\n", b"N" * 40, b"\t"]
+    for trial in range(60):
+        text = b"".join(pieces[int(rng.integers(0, len(pieces)))] for _ in range(int(rng.integers(0, 60))))
+        for limit in (0, 16, 41):
+            assert _gpu_read_all(text, limit) == _oracle_read_all(text, limit or 4096), (text, limit)
