@@ -15,3 +15,4 @@ GapSymbol = ord("-")  # package variable (align.go:3); assign bio_amd.GapSymbol 
 Seq = bytes  # seq.go:18
 from .fasta import FASTAReader, FASTASeq, FastaBatch, NewFASTAReader, ReadFASTA, ReadFASTAFile  # noqa: F401,E402
 from .distance import AlignDist, AlignScores, AlignScoresSharded, DistanceMatrix, pair_ranges  # noqa: F401,E402
+from .assembly import AlignLongOverlap  # noqa: F401,E402

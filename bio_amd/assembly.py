@@ -1,0 +1,89 @@
+"""Greedy fragment assembly on real overlap alignments.
+
+The reference's AlignLong (align_long.go:17-90) finds overlaps by exact substring search -- the last half of s must
+occur in t verbatim (align_long.go:35-45) -- so one read error breaks the assembly.  AlignLongOverlap keeps the
+reference's greedy merge (steps 2-4, align_long.go:46-89) statement by statement and replaces step 1 by ONE batch of
+"overlap" alignments (suffix of s against prefix of t, align_pair.go:184-195) over all ordered pairs of fragments
+on the GPU.  Only scores and end cells come back (BIOALIGN_TRACE_OPS records: the end cell's column is the length
+of t's prefix inside the overlap); no traces are expanded.
+
+This changes behaviour on purpose (an overlap may contain mismatches and gaps), which is why SURVEY ranks it last.
+On error-free reads it returns what AlignLong returns.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native
+from .subst_matrix import MatchAligner, score_table
+
+
+def overlap_end_cells(ss, pairs, a, indelPenalty: int):
+    """Overlap alignments of (ss[si], ss[ti]) for every (si, ti) in pairs -> (scores, j_end): int64 arrays; j_end =
+    length of the prefix of ss[ti] that the alignment covers (column of the end cell, align_pair.go:169-182)."""
+    from .align import _gap, engine, pack_sequences
+
+    d1, o1 = pack_sequences([ss[si] for si, _ in pairs])
+    d2, o2 = pack_sequences([ss[ti] for _, ti in pairs])
+    table, code1, code2 = score_table(a, np.unique(d1).tolist(), np.unique(d2).tolist())
+    pb = _native.PackedBatch(d1, o1, d2, o2, "overlap", table, code1, code2, indelPenalty, indelPenalty,
+                             gap_symbol=_gap(), flags=_native.TRACE_OPS)
+    scores, t1, _, t_off, _ = engine().batch(pb)
+    # record = uint32 i, uint32 j of the end cell, then the moves (include/bioalign.h); records are 4-byte aligned
+    words = t1[:len(t1) // 4 * 4].view(np.uint32)
+    j_end = words[(t_off // 4 + 1).astype(np.int64)].astype(np.int64)
+    return np.asarray(scores, dtype=np.int64), j_end
+
+
+def AlignLongOverlap(ss, a=None, indelPenalty: int = 2, minScorePerColumn: float = 0.8, end_cells=None) -> bytes:
+    """AlignLong (align_long.go:17) with alignment-based overlaps.  All fragments have the same length; an overlap
+    counts when it covers at least half a fragment of t (the reference's requirement, align_long.go:10-13) and
+    scores at least minScorePerColumn per covered column of t.  -> the assembled string, or b"" if the fragments
+    do not assemble into one.
+
+    end_cells(ss, pairs, a, indelPenalty) -> (scores, j_end): the default is the GPU batch; there is no CPU
+    fallback (the CPU test of the merge logic injects the oracle explicitly)."""
+    ss = [bytes(s) for s in ss]
+    if len(ss) == 0:
+        return b""
+    if len(ss) == 1:
+        return ss[0]
+    a = a if a is not None else MatchAligner(1, -1)
+    half = len(ss[0]) // 2
+    # 1. pairwise overlap alignments of all fragments (the reference skips t == s, align_long.go:38-40)
+    pairs = [(si, ti) for si in range(len(ss)) for ti in range(len(ss)) if ss[ti] != ss[si]]
+    overlaps = []
+    if pairs:
+        scores, j_end = (end_cells or overlap_end_cells)(ss, pairs, a, indelPenalty)
+        for (si, ti), sc, j in zip(pairs, scores.tolist(), j_end.tolist()):
+            if j >= half and j > 0 and sc >= minScorePerColumn * j:
+                overlaps.append([si, ti, j - half])  # x + half = overlap, as in the reference
+    left = 0
+    for _ in range(len(ss), 1, -1):
+        # 2. the two fragments with the largest overlap (first one wins ties, align_long.go:51-61)
+        x_max, o_max = -1, 0
+        for i, (si, ti, x) in enumerate(overlaps):
+            s, t = ss[si], ss[ti]
+            if s == b"" or t == b"" or t == s:
+                continue
+            if x > x_max:
+                x_max, o_max = x, i
+        if x_max == -1:
+            return b""
+        # 3. merge them
+        left, right = overlaps[o_max][0], overlaps[o_max][1]
+        ss[left] += ss[right][x_max + half:]
+        ss[right] = b""
+        # overlaps from si are deleted (swap with the last), overlaps from ti become overlaps from si
+        i = 0
+        while i < len(overlaps):
+            if overlaps[i][0] == left:
+                last = len(overlaps) - 1
+                if i < last:
+                    overlaps[i] = overlaps[last]
+                overlaps.pop()
+                continue
+            if overlaps[i][0] == right:
+                overlaps[i][0] = left
+            i += 1
+    return ss[left]

@@ -354,3 +354,85 @@ class FASTAReader:
                 seq += line
             # else: initial data without a header is ignored
         return header, seq, err
+
+
+def AlignLong(ss):
+    """align_long.go:17-90 restated statement by statement (strings as bytes).  No test of the reference covers
+    it: parity unpinned beyond this reading."""
+    ss = [bytes(s) for s in ss]
+    if len(ss) == 0:
+        return b""
+    if len(ss) == 1:
+        return ss[0]
+    half = len(ss[0]) // 2
+    overlaps = []
+    for si, s in enumerate(ss):
+        s_suf = s[len(s) - half:]
+        for ti, t in enumerate(ss):
+            if t == s:
+                continue
+            x = t.find(s_suf)
+            if x >= 0:
+                overlaps.append([si, ti, x])
+    return _greedy_merge(ss, overlaps, half)
+
+
+def _greedy_merge(ss, overlaps, half):
+    """align_long.go:46-89"""
+    left = 0
+    for _ in range(len(ss), 1, -1):
+        x_max, o_max = -1, 0
+        for i, o in enumerate(overlaps):
+            s, t = ss[o[0]], ss[o[1]]
+            if s == b"" or t == b"" or t == s:
+                continue
+            if o[2] > x_max:
+                x_max, o_max = o[2], i
+        if x_max == -1:
+            return b""
+        left, right = overlaps[o_max][0], overlaps[o_max][1]
+        ss[left] = ss[left] + ss[right][x_max + half:]
+        ss[right] = b""
+        i = 0
+        while i < len(overlaps):
+            if overlaps[i][0] == left:
+                last = len(overlaps) - 1
+                if i < last:
+                    overlaps[i] = overlaps[last]
+                del overlaps[last]
+                continue
+            if overlaps[i][0] == right:
+                overlaps[i][0] = left
+            i += 1
+    return ss[left]
+
+
+def overlap_end_cells(ss, pairs, a: Aligner, indel: int):
+    """Score and end column of AlignPair("overlap", ss[si], ss[ti]) (align_pair.go:184-195): the end column is the
+    number of symbols of t in the trace (the walk ends in column 0, align_pair.go:186-188)."""
+    scores, j_end = [], []
+    g = bytes([lib().bo_get_gap_symbol()])
+    for si, ti in pairs:
+        sc, t1, t2 = AlignPair("overlap", ss[si], ss[ti], a, indel)
+        scores.append(sc)
+        j_end.append(0 if t2 is None else len(t2) - t2.count(g))
+    return np.array(scores, dtype=np.int64), np.array(j_end, dtype=np.int64)
+
+
+def AlignLongOverlap(ss, a: Aligner, indel: int, min_score_per_column: float = 0.8):
+    """AlignLong with step 1 replaced by overlap alignments (no counterpart in the reference:
+    this is the checker of the product's bio_amd.AlignLongOverlap, built on the oracle's AlignPair)."""
+    ss = [bytes(s) for s in ss]
+    if len(ss) == 0:
+        return b""
+    if len(ss) == 1:
+        return ss[0]
+    half = len(ss[0]) // 2
+    pairs = [(si, ti) for si in range(len(ss)) for ti in range(len(ss)) if ss[ti] != ss[si]]
+    overlaps = []
+    if pairs:
+        scores, j_end = overlap_end_cells(ss, pairs, a, indel)
+        for (si, ti), sc, j in zip(pairs, scores.tolist(), j_end.tolist()):
+            if j >= half and j > 0 and sc >= min_score_per_column * j:
+                overlaps.append([si, ti, j - half])
+    return _greedy_merge(ss, overlaps, half)
