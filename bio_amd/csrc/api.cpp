@@ -1860,10 +1860,10 @@ extern "C" hipError_t ba_launch_pair_offsets(const uint64_t *off, uint64_t c0, u
 // copied in).  The plan sees lengths only (virtual offsets); where each pair's sequences lie in the list is
 // computed on the device (ba_pair_offsets_kernel).
 int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in, const uint64_t *off,
-                    const uint8_t *h_list, const uint8_t *d_list, const uint64_t *d_off, int64_t *scores, uint64_t lo,
-                    uint64_t hi, std::string *err)
+                    const uint8_t *h_list, const uint8_t *d_list, const uint64_t *d_off, int64_t *scores, uint64_t base,
+                    uint64_t lo, uint64_t hi, std::string *err)
 {
-    // (scores: where pair 0's score would lie; the caller has rebased it for a range that starts elsewhere)
+    // (scores[0] is pair `base` of the numbering)
     bioalign_ctx local;  // (as run_share: concurrent shares do not race on the error string)
     local.devices = ctx->devices;
     local.pool = ctx->pool;
@@ -1945,7 +1945,7 @@ int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in
         rc = bioalign_plan_run(pl, d_list, q1.as<uint64_t>(), d_list, q2.as<uint64_t>(), sc.as<int64_t>(), nullptr,
                                nullptr, nullptr, nullptr, st);
         if (rc) goto done;
-        AP_TRY(hipMemcpyAsync(scores + c0, sc.p, N * 8, hipMemcpyDeviceToHost, st));
+        AP_TRY(hipMemcpyAsync(scores + (c0 - base), sc.p, N * 8, hipMemcpyDeviceToHost, st));
         AP_TRY(hipStreamSynchronize(st));
         bioalign_plan_destroy(pl);
         pl = nullptr;
@@ -1978,7 +1978,6 @@ int all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, const uint64_t *off
     if (!scores) return ctx->fail(BIOALIGN_EINVAL, "null scores buffer");
     for (uint64_t k = 0; k < n; ++k)
         if (off[k + 1] < off[k]) return ctx->fail(BIOALIGN_EINVAL, "offsets must be non-decreasing (sequence %llu)", (unsigned long long)k);
-    scores -= first;  // indexed by pair number from here on (never dereferenced outside [first, first + count))
     // Ranges of pairs balanced by cell count: one per device (as bioalign_batch; a list that already lies on one
     // device stays there), and for large lists several per device, each driven by a host thread of its own, so
     // that the host work of one range (lengths, plan) overlaps the kernels of another.  BIOALIGN_HOST_SHARES
@@ -2011,8 +2010,8 @@ int all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, const uint64_t *off
     std::vector<int> rcs(D, 0);
     std::vector<std::string> errs(D);
     auto share = [&](int d) {
-        rcs[d] = all_pairs_share(ctx, d_list ? d_list_dev : d / per_dev, in, off, h_list, d_list, d_off, scores, cut[d],
-                                 cut[d + 1], &errs[d]);
+        rcs[d] = all_pairs_share(ctx, d_list ? d_list_dev : d / per_dev, in, off, h_list, d_list, d_off, scores, first,
+                                 cut[d], cut[d + 1], &errs[d]);
     };
     if (D == 1) {
         share(0);
