@@ -27,6 +27,7 @@ extern "C" size_t ba_dp_linear_lds_bytes(int nb, int nb4, int na_pad, int R, int
 extern "C" hipError_t ba_launch_pack(const BaPackParams &P, hipStream_t st);
 extern "C" hipError_t ba_launch_dp_linear(const BaDpParams &P, int mode, int R, int K, int waves, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_linear(const BaTraceParams &P, int mode, int R, int K, int phases, hipStream_t st);
+extern "C" hipError_t ba_launch_iota(uint32_t *out, uint64_t n, hipStream_t st);
 extern "C" hipError_t ba_launch_len_partial(const uint64_t *len, uint64_t n, uint64_t *part, hipStream_t st);
 extern "C" hipError_t ba_launch_len_apply(const uint64_t *len, uint64_t n, const uint64_t *part, uint64_t *t_off,
                                           uint64_t *dense_end, hipStream_t st);
@@ -295,12 +296,15 @@ extern "C" void bioalign_plan_destroy(bioalign_plan *pl)
 extern "C" uint64_t bioalign_plan_workspace_bytes(const bioalign_plan *pl) { return pl ? pl->ws_bytes : 0; }
 extern "C" uint64_t bioalign_plan_cells(const bioalign_plan *pl) { return pl ? pl->cells : 0; }
 
-static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
+// lens1 / lens2: the pairs' lengths when the caller has them already (bioalign_all_pairs: the plan then never looks at
+// in->s1_off / s2_off); null: taken from the offsets
+static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint32_t *lens1 = nullptr,
+                      const uint32_t *lens2 = nullptr)
 {
     bioalign_ctx *ctx = pl->ctx;
     if (in->mode < BIOALIGN_GLOBAL || in->mode > BIOALIGN_OVERLAP)
         return ctx->fail(BIOALIGN_EINVAL, "unknown mode %d", in->mode);
-    if (!in->s1_off || !in->s2_off || !in->score_table || !in->code1 || !in->code2)
+    if ((!lens1 && (!in->s1_off || !in->s2_off)) || !in->score_table || !in->code1 || !in->code2)
         return ctx->fail(BIOALIGN_EINVAL, "null offsets / score table / code maps");
     if (in->na <= 0 || in->nb <= 0 || in->na > 255 || in->nb > 255)
         return ctx->fail(BIOALIGN_EINVAL, "alphabet sizes must be in 1..255 (got %d, %d)", in->na, in->nb);
@@ -324,26 +328,38 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         return ctx->fail(BIOALIGN_EUNSUPPORTED, "gap_open %d < gap_extend %d is outside the fast kernels",
                          pl->gap_open, pl->gap_ext);
 
+    const bool pb_timing = env_u64("BIOALIGN_TIMING", 0) > 1;
+    const auto pb_t0 = std::chrono::steady_clock::now();
+    auto pb_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pb_t0).count(); };
+    double pb_a = 0, pb_b = 0, pb_c = 0, pb_d = 0;
     // shapes
-    std::vector<uint32_t> len1(N), len2(N);
+    std::vector<uint32_t> len1_own, len2_own;
+    if (!lens1) {
+        len1_own.resize(N);
+        len2_own.resize(N);
+        for (uint64_t p = 0; p < N; ++p) {
+            if (in->s1_off[p + 1] < in->s1_off[p] || in->s2_off[p + 1] < in->s2_off[p])
+                return ctx->fail(BIOALIGN_EINVAL, "offsets must be non-decreasing (pair %llu)", (unsigned long long)p);
+            const uint64_t a = in->s1_off[p + 1] - in->s1_off[p], b = in->s2_off[p + 1] - in->s2_off[p];
+            len1_own[p] = (uint32_t)std::min<uint64_t>(a, 0xffffffffu);
+            len2_own[p] = (uint32_t)std::min<uint64_t>(b, 0xffffffffu);
+        }
+        if (N && (in->s1_off[0] != 0 || in->s2_off[0] != 0))
+            return ctx->fail(BIOALIGN_EINVAL, "offsets must start at 0");
+    }
+    const uint32_t *const len1 = lens1 ? lens1 : len1_own.data(), *const len2 = lens1 ? lens2 : len2_own.data();
     uint64_t max_n = 0, max_m = 0, min_nm_max = 0;
     for (uint64_t p = 0; p < N; ++p) {
-        if (in->s1_off[p + 1] < in->s1_off[p] || in->s2_off[p + 1] < in->s2_off[p])
-            return ctx->fail(BIOALIGN_EINVAL, "offsets must be non-decreasing (pair %llu)", (unsigned long long)p);
-        const uint64_t a = in->s1_off[p + 1] - in->s1_off[p], b = in->s2_off[p + 1] - in->s2_off[p];
-        if (a > 0x7fffffu || b > 0x7fffffu)
-            return ctx->fail(BIOALIGN_EUNSUPPORTED, "pair %llu is longer than 8M symbols; use bioalign_long",
-                             (unsigned long long)p);
-        len1[p] = (uint32_t)a;
-        len2[p] = (uint32_t)b;
-        pl->lens_hash = (pl->lens_hash ^ (a * 0x9e3779b97f4a7c15ull + b)) * 0x100000001b3ull;
+        const uint64_t a = len1[p], b = len2[p];
+        // (a sum of independent terms: no multiply chain from pair to pair)
+        pl->lens_hash += ((a * 0x9e3779b97f4a7c15ull + b) ^ (p * 0x100000001b3ull)) * (2 * p + 1);
         max_n = std::max(max_n, a);
         max_m = std::max(max_m, b);
         min_nm_max = std::max(min_nm_max, std::min(a, b));
         pl->cells += a * b;
     }
-    if (N && (in->s1_off[0] != 0 || in->s2_off[0] != 0))
-        return ctx->fail(BIOALIGN_EINVAL, "offsets must start at 0");
+    if (max_n > 0x7fffffu || max_m > 0x7fffffu)
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "a pair is longer than 8M symbols; use bioalign_long");
 
     // int8 profile with the bias folded in (kernels.hip: biased score space)
     // (affine: every level is biased by ext*(i+j) and the strip keeps H' - (open - ext), kernels_affine.hip)
@@ -408,15 +424,20 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     const int chw = 4 * (R * pl->K / 32);  // residue dwords per lane per group of 4 columns
     const uint64_t cpw = 32 / R;           // affine: columns per decision word
 
+    pb_a = pb_ms();
     // shape-sort the pairs; identical shapes become bundles of <= 64
-    std::vector<uint32_t> perm(N);
-    std::iota(perm.begin(), perm.end(), 0u);
+    // (one shape for all: the order is the caller's, written on the device -- no host array, no copy)
     bool uniform = true;
     for (uint64_t p = 1; p < N && uniform; ++p) uniform = len1[p] == len1[0] && len2[p] == len2[0];
-    if (!uniform)
+    std::vector<uint32_t> perm;
+    if (!uniform) {
+        perm.resize(N);
+        std::iota(perm.begin(), perm.end(), 0u);
         std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) {
             return len1[a] != len1[b] ? len1[a] < len1[b] : len2[a] < len2[b];
         });
+    }
+    auto at = [&](uint64_t q) -> uint64_t { return uniform ? q : perm[q]; };
     uint64_t budget = env_u64("BIOALIGN_WORKSPACE_BYTES", 96ull << 30);
     pl->bundles.clear();
     pl->chunks.clear();
@@ -426,9 +447,12 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
     const bool use_rec = !pl->affine && !pl->score_only;
     uint32_t chunk_begin = 0;
     for (uint64_t q = 0; q < N;) {
-        const uint32_t n = len1[perm[q]], m = len2[perm[q]];
+        const uint32_t n = len1[at(q)], m = len2[at(q)];
         uint64_t e = q + 1;
-        while (e < N && e - q < BA_WAVE && len1[perm[e]] == n && len2[perm[e]] == m) ++e;
+        if (uniform)
+            e = std::min<uint64_t>(N, q + BA_WAVE);
+        else
+            while (e < N && e - q < BA_WAVE && len1[perm[e]] == n && len2[perm[e]] == m) ++e;
         const uint64_t strips = (n + R - 1) / R;
         const uint64_t sz_s1w = strips * R / 4 * 64, sz_s2w = (uint64_t)((m + 3) / 4) * 64;
         // boundary deltas: two buffers (strip parity) of ceil(m / F) words per lane, F >= 4
@@ -498,6 +522,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         }
     }
 
+    pb_b = pb_ms();
     // device memory
     HIP_TRY(ctx, hipSetDevice(ctx->devices[pl->device]));
     int rc;
@@ -554,14 +579,30 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         if (ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, pl->waves, pl->nib) > 160 * 1024)
             return ctx->fail(BIOALIGN_EUNSUPPORTED, "alphabet of %d column symbols needs more LDS than a CU has", pl->nb);
     }
-    if (!pl->bundles.empty())
-        HIP_TRY(ctx, hipMemcpy(pl->d_bundles, pl->bundles.data(), pl->bundles.size() * sizeof(BaBundle),
-                               hipMemcpyHostToDevice));
-    if (N) HIP_TRY(ctx, hipMemcpy(pl->d_perm, perm.data(), N * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(pl->d_code1, in->code1, 256, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(pl->d_code2, in->code2, 256, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(pl->d_table, in->score_table, (size_t)pl->na * pl->nb * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(pl->d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+    pb_c = pb_ms();
+    {
+        // on a stream of the plan's own that does not synchronise with the null stream: a plan that is built while
+        // another range's kernels run (bioalign_batch, bioalign_all_pairs) does not wait for them
+        hipStream_t cs = nullptr;
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        hipError_t e = hipSuccess;
+        auto up = [&](void *dst, const void *src, size_t bytes) {
+            if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs);
+        };
+        up(pl->d_bundles, pl->bundles.data(), pl->bundles.size() * sizeof(BaBundle));
+        if (uniform) {
+            if (e == hipSuccess) e = ba_launch_iota(pl->d_perm, N, cs);
+        } else {
+            up(pl->d_perm, perm.data(), N * 4);
+        }
+        up(pl->d_code1, in->code1, 256);
+        up(pl->d_code2, in->code2, 256);
+        up(pl->d_table, in->score_table, (size_t)pl->na * pl->nb * 4);
+        up(pl->d_wt, wt.data(), wt.size() * 4);
+        if (e == hipSuccess) e = hipStreamSynchronize(cs);  // (the sources are locals; runs come on the caller's streams)
+        (void)hipStreamDestroy(cs);
+        if (e != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "plan upload failed: %s", hipGetErrorString(e));
+    }
     // Large batches: cut every chunk into slices so that the (latency-bound) traceback of one slice
     // overlaps the (VALU-bound) DP of the next.  Slices have disjoint workspace by construction.
     {
@@ -579,6 +620,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
             HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_side_done, hipEventDisableTiming));
         }
     }
+    pb_d = pb_ms();
     const size_t pool = 256;
     pl->ev0.resize(pool);
     pl->ev1.resize(pool);
@@ -586,6 +628,9 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in)
         HIP_TRY(ctx, hipEventCreate(&pl->ev0[c]));
         HIP_TRY(ctx, hipEventCreate(&pl->ev1[c]));
     }
+    if (pb_timing)
+        fprintf(stderr, "bioalign plan_build %llu pairs: lengths %.2f ms, sort + bundles %.2f, alloc %.2f, copies %.2f, events %.2f\n",
+                (unsigned long long)N, pb_a, pb_b - pb_a, pb_c - pb_b, pb_d - pb_c, pb_ms() - pb_d);
     return 0;
 }
 
@@ -1875,7 +1920,7 @@ int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in
     bioalign_plan *pl = nullptr;
     int rc = 0;
     PoolBuf list, loff, q1, q2, sc;
-    std::vector<uint64_t> v1, v2;
+    std::vector<uint32_t> v1, v2;
     const bool timing = env_u64("BIOALIGN_TIMING", 0) != 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) {
@@ -1907,19 +1952,22 @@ int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in
         if ((rc = q1.alloc(&local, hip_dev, (cap + 1) * 8)) != 0 || (rc = q2.alloc(&local, hip_dev, (cap + 1) * 8)) != 0 ||
             (rc = sc.alloc(&local, hip_dev, cap * 8)) != 0)
             goto done;
-        v1.resize(cap + 1);
-        v2.resize(cap + 1);
+        v1.resize(cap);
+        v2.resize(cap);
     }
     for (uint64_t c0 = lo; c0 < hi; c0 += CH) {
         const uint64_t N = std::min(CH, hi - c0);
         AP_TRY(ba_launch_pair_offsets(d_off, c0, N, q1.as<uint64_t>(), q2.as<uint64_t>(), st));
         uint64_t i, j;
         pair_of(c0, &i, &j);
-        v1[0] = v2[0] = 0;
-        for (uint64_t k = 0; k < N; ++k) {
-            v1[k + 1] = v1[k] + (off[i + 1] - off[i]);
-            v2[k + 1] = v2[k] + (off[j + 1] - off[j]);
-            if (++j == i) {
+        for (uint64_t k = 0; k < N;) {  // row i: its own length against the lengths of sequences j .. i - 1
+            const uint32_t li = (uint32_t)std::min<uint64_t>(off[i + 1] - off[i], 0xffffffffu);
+            const uint64_t stop = std::min<uint64_t>(N, k + (i - j));
+            for (; k < stop; ++k, ++j) {
+                v1[k] = li;
+                v2[k] = (uint32_t)std::min<uint64_t>(off[j + 1] - off[j], 0xffffffffu);
+            }
+            if (j == i) {
                 ++i;
                 j = 0;
             }
@@ -1928,15 +1976,14 @@ int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in
         t_mark = now();
         bioalign_batch_t sub = *in;
         sub.s1 = sub.s2 = nullptr;
-        sub.s1_off = v1.data();
-        sub.s2_off = v2.data();
+        sub.s1_off = sub.s2_off = nullptr;
         sub.n_pairs = N;
         sub.flags = BIOALIGN_SCORE_ONLY;
         pl = new bioalign_plan;
         pl->ctx = &local;
         pl->device = dev_index;
         pl->pool = ctx->pool;
-        if (plan_build(pl, &sub) != 0) {
+        if (plan_build(pl, &sub, v1.data(), v2.data()) != 0) {
             rc = local.code ? local.code : BIOALIGN_EINVAL;
             goto done;
         }

@@ -987,3 +987,21 @@ extern "C" hipError_t ba_launch_pair_offsets(const uint64_t *off, uint64_t c0, u
     hipLaunchKernelGGL(ba_pair_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, off, c0, n, q1, q2);
     return hipGetLastError();
 }
+
+// out[k] = k: the pair order of a batch whose pairs all have one shape (nothing to sort)
+__global__ void __launch_bounds__(256) ba_iota_kernel(uint32_t *__restrict__ out, uint64_t n)
+{
+    const uint64_t k = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (k + 4 <= n) {
+        *reinterpret_cast<uint4 *>(out + k) = make_uint4((uint32_t)k, (uint32_t)k + 1, (uint32_t)k + 2, (uint32_t)k + 3);
+    } else {
+        for (uint64_t q = k; q < n; ++q) out[q] = (uint32_t)q;
+    }
+}
+
+extern "C" hipError_t ba_launch_iota(uint32_t *out, uint64_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(ba_iota_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, out, n);
+    return hipGetLastError();
+}
