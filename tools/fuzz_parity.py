@@ -1,0 +1,163 @@
+"""Randomised parity run: the HIP path against the oracle over random shapes, alphabets, scorings, gap models and
+modes, for a given number of seconds.  Prints one line per batch group and a summary; exits 1 at the first
+difference (with the inputs that show it).  Not a test (the oracle is the checker here, as in tests/): a tool to
+spend GPU minutes on looking for inputs the fixed tests do not cover.
+
+usage: python tools/fuzz_parity.py --seconds 240 --seed 1
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bio_amd  # noqa: E402
+from bio_amd import _native, pack_sequences, score_table  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+MODES = ("global", "local", "fitting", "overlap")
+
+
+def random_batch(rng):
+    kind = rng.choice(["dna", "dna", "protein", "binary"])
+    alpha = {"dna": b"ACGT", "protein": b"ARNDCQEGHILKMFPSTWYV", "binary": b"AB"}[kind]
+    al = np.frombuffer(alpha, dtype=np.uint8)
+    n_pairs = int(rng.choice([1, 3, 64, 65, 200, 700]))
+    shape = rng.choice(["uniform", "ragged", "few_shapes", "related"])
+    hi = int(rng.choice([8, 40, 100, 200, 330]))
+    s1s, s2s = [], []
+    shapes = [(int(rng.integers(0, hi + 1)), int(rng.integers(0, hi + 1))) for _ in range(4)]
+    un, um = int(rng.integers(1, hi + 1)), int(rng.integers(1, hi + 1))
+    for _ in range(n_pairs):
+        if shape == "uniform":
+            n, m = un, um
+        elif shape == "few_shapes":
+            n, m = shapes[int(rng.integers(0, 4))]
+        else:
+            n, m = int(rng.integers(0, hi + 1)), int(rng.integers(0, hi + 1))
+        a = al[rng.integers(0, len(al), n)]
+        if shape == "related" and n:
+            # s2 = s1 with a few edits, cut to m: long diagonal runs, ties between paths
+            b = a.copy()
+            for _ in range(int(rng.integers(0, 6))):
+                p = int(rng.integers(0, len(b))) if len(b) else 0
+                op = rng.integers(0, 3)
+                if op == 0 and len(b):
+                    b[p] = al[rng.integers(0, len(al))]
+                elif op == 1 and len(b):
+                    b = np.delete(b, p)
+                else:
+                    b = np.insert(b, p, al[rng.integers(0, len(al))])
+            b = b[:max(m, 1)] if rng.integers(0, 2) else b
+        else:
+            b = al[rng.integers(0, len(al), m)]
+        s1s.append(a.tobytes())
+        s2s.append(b.tobytes())
+    return kind, s1s, s2s
+
+
+def random_scoring(rng, kind):
+    if kind == "protein" and rng.integers(0, 3):
+        name = rng.choice(["Blosum62", "Pam250"])
+        pa = getattr(bio_amd, name)
+        oa = getattr(O, name)()
+        gap = int(rng.integers(1, 12))
+        return name, pa, oa, gap
+    match, mismatch = int(rng.integers(0, 6)), -int(rng.integers(0, 6))
+    gap = int(rng.integers(0, 8))
+    return f"match {match} mismatch {mismatch}", bio_amd.MatchAligner(match, mismatch), O.MatchAligner(match, mismatch), gap
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--long", action="store_true", help="long mode (bioalign_long) on single pairs instead of batches")
+    ap.add_argument("--stripes", type=int, default=0, help="with --long: force this many column stripes")
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    if args.long:
+        if args.stripes:
+            os.environ["BIOALIGN_LONG_STRIPES"] = str(args.stripes)
+        k = 0
+        al = np.frombuffer(b"ACGT", dtype=np.uint8)
+        while time.time() < t_end:
+            hi = int(rng.choice([70, 600, 1500, 4000]))
+            n, m = int(rng.integers(1, hi + 1)), int(rng.integers(1, hi + 1))
+            nsym = int(rng.integers(1, 5))
+            a = al[rng.integers(0, nsym, n)]
+            if rng.integers(0, 2):
+                b = a.copy()
+                for _ in range(int(rng.integers(0, 30))):
+                    p = int(rng.integers(0, max(len(b), 1)))
+                    b = np.delete(b, p) if rng.integers(0, 2) and len(b) > 1 else np.insert(b, p, al[rng.integers(0, nsym)])
+                b = b[:max(m, 1)]
+            else:
+                b = al[rng.integers(0, nsym, m)]
+            x, y = a.tobytes(), b.tobytes()
+            match, mismatch, gap = int(rng.integers(0, 4)), -int(rng.integers(0, 4)), int(rng.integers(0, 5))
+            mode = ("global", "fitting", "overlap")[int(rng.integers(0, 3))]
+            try:
+                got = bio_amd.AlignPairLong(mode, x, y, bio_amd.MatchAligner(match, mismatch), gap)
+            except _native.BioAlignError as e:
+                if e.code == _native.EUNSUPPORTED:
+                    continue
+                raise
+            want = O.AlignPair(mode, x, y, O.MatchAligner(match, mismatch), gap)
+            if got != want:
+                print("MISMATCH", dict(mode=mode, match=match, mismatch=mismatch, gap=gap, s1=x, s2=y, want_score=want[0], got_score=got[0]), flush=True)
+                sys.exit(1)
+            k += 1
+            if k % 100 == 0:
+                print(f"{k} long pairs, all equal", flush=True)
+        print(f"done: {k} long pairs, all equal (seed {args.seed}, stripes {args.stripes})", flush=True)
+        return
+    batches = pairs = unsupported = 0
+    eng = bio_amd.engine()
+    while time.time() < t_end:
+        kind, s1s, s2s = random_batch(rng)
+        name, pa, oa, gap = random_scoring(rng, kind)
+        affine = bool(rng.integers(0, 3) == 0)
+        ext = int(rng.integers(0, gap + 1)) if affine else gap
+        if affine and ext == gap:
+            affine = False
+        mode = MODES[int(rng.integers(0, 4))]
+        form = rng.choice(["strings", "ops", "scores"]) if not affine else rng.choice(["strings", "scores"])
+        d1, o1 = pack_sequences(s1s)
+        d2, o2 = pack_sequences(s2s)
+        tbl, c1, c2 = score_table(pa, np.unique(d1).tolist(), np.unique(d2).tolist())
+        flags = {"strings": 0, "ops": _native.TRACE_OPS, "scores": _native.SCORE_ONLY}[form]
+        pb = _native.PackedBatch(d1, o1, d2, o2, mode, tbl, c1, c2, gap, ext, flags=flags)
+        try:
+            scores, t1, t2, t_off, t_len = eng.batch(pb)
+        except _native.BioAlignError as e:
+            if e.code == _native.EUNSUPPORTED:
+                unsupported += 1
+                continue
+            raise
+        for p, (x, y) in enumerate(zip(s1s, s2s)):
+            want = O.AlignAffine(mode, x, y, oa, gap, ext) if affine else O.AlignPair(mode, x, y, oa, gap)
+            ok = int(scores[p]) == want[0]
+            if ok and form != "scores":
+                o, ln = int(t_off[p]), int(t_len[p])
+                if form == "ops":
+                    g1, g2 = _native.expand_ops(x, y, t1, o, ln)
+                else:
+                    g1, g2 = t1[o:o + ln].tobytes(), t2[o:o + ln].tobytes()
+                ok = (g1 or None, g2 or None) == (want[1], want[2])
+            if not ok:
+                print("MISMATCH", dict(mode=mode, scoring=name, gap=gap, ext=ext, affine=affine, form=form, pair=p,
+                                       s1=x, s2=y, want=want, got_score=int(scores[p])), flush=True)
+                sys.exit(1)
+        batches += 1
+        pairs += len(s1s)
+        if batches % 50 == 0:
+            print(f"{batches} batches, {pairs} pairs, {unsupported} outside the kernels' range, all equal", flush=True)
+    print(f"done: {batches} batches, {pairs} pairs, {unsupported} outside the kernels' range, all equal (seed {args.seed})", flush=True)
+
+
+if __name__ == "__main__":
+    main()
