@@ -20,13 +20,19 @@ from oracle import oracle as O  # noqa: E402
 MODES = ("global", "local", "fitting", "overlap")
 
 
+SIZES = {"default": ([1, 3, 64, 65, 200, 700], [8, 40, 100, 200, 330]),
+         "big": ([66000, 70000, 140000], [10, 24, 40]),     # several host-driven ranges per device
+         "wide": ([1, 5, 64, 90], [700, 1500, 2600])}        # many strips, long rows
+PROFILE = "default"
+
+
 def random_batch(rng):
     kind = rng.choice(["dna", "dna", "protein", "binary"])
     alpha = {"dna": b"ACGT", "protein": b"ARNDCQEGHILKMFPSTWYV", "binary": b"AB"}[kind]
     al = np.frombuffer(alpha, dtype=np.uint8)
-    n_pairs = int(rng.choice([1, 3, 64, 65, 200, 700]))
+    n_pairs = int(rng.choice(SIZES[PROFILE][0]))
     shape = rng.choice(["uniform", "ragged", "few_shapes", "related"])
-    hi = int(rng.choice([8, 40, 100, 200, 330]))
+    hi = int(rng.choice(SIZES[PROFILE][1]))
     s1s, s2s = [], []
     shapes = [(int(rng.integers(0, hi + 1)), int(rng.integers(0, hi + 1))) for _ in range(4)]
     un, um = int(rng.integers(1, hi + 1)), int(rng.integers(1, hi + 1))
@@ -74,11 +80,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--profile", default="default", choices=sorted(SIZES), help="batch sizes and lengths to draw from")
     ap.add_argument("--long", action="store_true", help="long mode (bioalign_long) on single pairs instead of batches")
     ap.add_argument("--stripes", type=int, default=0, help="with --long: force this many column stripes")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
+    global PROFILE
+    PROFILE = args.profile
     if args.long:
         if args.stripes:
             os.environ["BIOALIGN_LONG_STRIPES"] = str(args.stripes)
@@ -154,7 +163,7 @@ def main():
                 sys.exit(1)
         batches += 1
         pairs += len(s1s)
-        if batches % 50 == 0:
+        if batches % (50 if PROFILE == "default" else 5) == 0:
             print(f"{batches} batches, {pairs} pairs, {unsupported} outside the kernels' range, all equal", flush=True)
     print(f"done: {batches} batches, {pairs} pairs, {unsupported} outside the kernels' range, all equal (seed {args.seed})", flush=True)
 
