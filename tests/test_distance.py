@@ -63,7 +63,7 @@ def test_all_pairs_matches_oracle(mode, affine):
     import bio_amd
 
     rng = np.random.default_rng(["global", "local", "fitting", "overlap"].index(mode) * 2 + int(affine))
-    l = _random_list(rng, 37, 0 if mode == "global" else 1, 70)
+    l = _random_list(rng, 37, 0, 70) + [b"", b"A", b""]
     if affine:
         f = bio_amd.AlignDist(mode, bio_amd.MatchAligner(2, -3), 5, 1)
         oa = O.MatchAligner(2, -3)
