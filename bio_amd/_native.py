@@ -19,6 +19,7 @@ MODES = {"global": GLOBAL, "local": LOCAL, "fitting": FITTING, "overlap": OVERLA
 SCORE_ONLY = 1
 DENSE_TRACES = 2  # plans: traces back to back in pair order instead of in per-pair slots
 TRACE_OPS = 4     # compact move records in t1 instead of the two gapped strings (include/bioalign.h)
+END_CELLS = 8     # with SCORE_ONLY: t_off / t_len receive the end cell (row, column) of every pair
 EINVAL, ENODEVICE, ENOMEM, EHIP, EUNSUPPORTED = -1, -2, -3, -4, -5
 
 # every symbol include/bioalign.h declares
@@ -298,6 +299,8 @@ class Engine:
             t_len = np.zeros(max(n, 1), dtype=np.uint64)
         r = Result()
         r.scores = scores.ctypes.data
+        if score_only and pb.c.flags & END_CELLS:
+            r.t_off, r.t_len = t_off.ctypes.data, t_len.ctypes.data
         if not score_only:
             r.t1, r.t2 = t1.ctypes.data, t2.ctypes.data
             r.t_off, r.t_len = t_off.ctypes.data, t_len.ctypes.data

@@ -4,8 +4,8 @@ The reference's AlignLong (align_long.go:17-90) finds overlaps by exact substrin
 occur in t verbatim (align_long.go:35-45) -- so one read error breaks the assembly.  AlignLongOverlap keeps the
 reference's greedy merge (steps 2-4, align_long.go:46-89) statement by statement and replaces step 1 by ONE batch of
 "overlap" alignments (suffix of s against prefix of t, align_pair.go:184-195) over all ordered pairs of fragments
-on the GPU.  Only scores and end cells come back (BIOALIGN_TRACE_OPS records: the end cell's column is the length
-of t's prefix inside the overlap); no traces are expanded.
+on the GPU.  Only scores and end cells come back (BIOALIGN_SCORE_ONLY | BIOALIGN_END_CELLS: the end cell's column is
+the length of t's prefix inside the overlap); there is no traceback at all.
 
 This changes behaviour on purpose (an overlap may contain mismatches and gaps), which is why SURVEY ranks it last.
 On error-free reads it returns what AlignLong returns.
@@ -27,12 +27,9 @@ def overlap_end_cells(ss, pairs, a, indelPenalty: int):
     d2, o2 = pack_sequences([ss[ti] for _, ti in pairs])
     table, code1, code2 = score_table(a, np.unique(d1).tolist(), np.unique(d2).tolist())
     pb = _native.PackedBatch(d1, o1, d2, o2, "overlap", table, code1, code2, indelPenalty, indelPenalty,
-                             gap_symbol=_gap(), flags=_native.TRACE_OPS)
-    scores, t1, _, t_off, _ = engine().batch(pb)
-    # record = uint32 i, uint32 j of the end cell, then the moves (include/bioalign.h); records are 4-byte aligned
-    words = t1[:len(t1) // 4 * 4].view(np.uint32)
-    j_end = words[(t_off // 4 + 1).astype(np.int64)].astype(np.int64)
-    return np.asarray(scores, dtype=np.int64), j_end
+                             gap_symbol=_gap(), flags=_native.SCORE_ONLY | _native.END_CELLS)
+    scores, _, _, _, j_end = engine().batch(pb)  # t_len = column of the end cell (include/bioalign.h)
+    return np.asarray(scores, dtype=np.int64), j_end.astype(np.int64)
 
 
 def AlignLongOverlap(ss, a=None, indelPenalty: int = 2, minScorePerColumn: float = 0.8, end_cells=None) -> bytes:

@@ -157,6 +157,7 @@ struct bioalign_plan {
     int mode = 0;
     bool affine = false;
     bool score_only = false;
+    bool end_cells = false;  // score_only: the end cell of every pair goes to t_off (row) / t_len (column)
     int gap = 0, gap_open = 0, gap_ext = 0;
     uint8_t gap_symbol = '-';
     int na = 0, nb = 0, nb4 = 0, na_pad = 0;
@@ -314,6 +315,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
     pl->mode = in->mode;
     pl->affine = in->gap_open != in->gap_extend;
     pl->score_only = (in->flags & BIOALIGN_SCORE_ONLY) != 0;
+    pl->end_cells = pl->score_only && (in->flags & BIOALIGN_END_CELLS) != 0;
     pl->want_dense = (in->flags & BIOALIGN_DENSE_TRACES) != 0;
     pl->ops = !pl->score_only && (in->flags & BIOALIGN_TRACE_OPS) != 0;
     pl->gap = pl->gap_open = in->gap_open;
@@ -665,6 +667,9 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
     if (pl->n_pairs == 0) return 0;
     if (!d_s1_off || !d_s2_off || !d_scores)
         return ctx->fail(BIOALIGN_EINVAL, "null device pointer");
+    if (pl->end_cells && (!d_t_off || !d_t_len))
+        return ctx->fail(BIOALIGN_EINVAL, "BIOALIGN_END_CELLS needs t_off and t_len");
+    if (pl->score_only && !pl->end_cells) d_t_off = d_t_len = nullptr;  // (whatever the caller passed is not touched)
     if (!pl->score_only && (!d_t1 || (!d_t2 && !pl->ops) || !d_t_off || !d_t_len))
         return ctx->fail(BIOALIGN_EINVAL, "trace buffers are required unless BIOALIGN_SCORE_ONLY is set");
     hipStream_t st = (hipStream_t)stream;
@@ -893,6 +898,7 @@ static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *i
     t_plan = ms_since(t_start);
     auto t_mark = now();
     const bool traces = !pl->score_only;
+    const bool end_cells = pl->end_cells;
     const uint64_t bytes1 = o1[N], bytes2 = o2[N], cap = bytes1 + bytes2;
     const bool ops = pl->ops;
     // BIOALIGN_TRACE_OPS: the share's records go to the caller's t1 from byte ops_base(lo) on (see bioalign_ops_capacity)
@@ -932,6 +938,9 @@ static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *i
         if (!ops) SHARE_GET(d_t2, cap + 16);
         SHARE_GET(d_toff, N * 8);
         SHARE_GET(d_tlen, N * 8);
+    } else if (end_cells) {
+        SHARE_GET(d_toff, N * 8);
+        SHARE_GET(d_tlen, N * 8);
     }
 #undef SHARE_GET
     t_alloc = ms_since(t_mark);
@@ -953,6 +962,10 @@ static int run_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *i
         t_mark = now();
     }
     SHARE_TRY(hipMemcpyAsync(out->scores + lo, d_sc, N * 8, hipMemcpyDeviceToHost, st));
+    if (end_cells) {
+        SHARE_TRY(hipMemcpyAsync(out->t_off + lo, d_toff, N * 8, hipMemcpyDeviceToHost, st));
+        SHARE_TRY(hipMemcpyAsync(out->t_len + lo, d_tlen, N * 8, hipMemcpyDeviceToHost, st));
+    }
     if (traces) {
         toff.resize(N);
         tlen.resize(N);
@@ -1017,6 +1030,8 @@ extern "C" int bioalign_batch(bioalign_ctx *ctx, const bioalign_batch_t *in, bio
     const bool traces = !(in->flags & BIOALIGN_SCORE_ONLY);
     if (traces && (!out->t1 || (!out->t2 && !(in->flags & BIOALIGN_TRACE_OPS)) || !out->t_off || !out->t_len))
         return ctx->fail(BIOALIGN_EINVAL, "trace buffers are required unless BIOALIGN_SCORE_ONLY is set");
+    if (!traces && (in->flags & BIOALIGN_END_CELLS) && (!out->t_off || !out->t_len))
+        return ctx->fail(BIOALIGN_EINVAL, "BIOALIGN_END_CELLS needs t_off and t_len");
     if ((in->s1_off[N] && !in->s1) || (in->s2_off[N] && !in->s2))
         return ctx->fail(BIOALIGN_EINVAL, "null sequence bytes");
     // split the pairs into contiguous ranges balanced by cell count, one per device -- and, for

@@ -486,6 +486,10 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
             score = (int64_t)cur - (int64_t)g * (i + j);
         }
         P.scores[p] = score;
+        if (P.score_only && P.t_off) {  // BIOALIGN_END_CELLS: where the alignment ends, without a traceback
+            P.t_off[p] = (uint64_t)i;
+            P.t_len[p] = (uint64_t)j;
+        }
     }
     if (P.score_only) return;
 

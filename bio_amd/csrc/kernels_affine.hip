@@ -412,6 +412,10 @@ __global__ void __launch_bounds__(256) ba_trace_affine_kernel(BaTraceParams P)
         j = bb.j;
         V = bb.score;
         P.scores[p] = (int64_t)bb.score;
+        if (P.score_only && P.t_off) {  // BIOALIGN_END_CELLS
+            P.t_off[p] = (uint64_t)i;
+            P.t_len[p] = (uint64_t)j;
+        }
     }
     if (P.score_only) return;
 

@@ -46,15 +46,21 @@ enum {
                                        when the batch runs in one workspace chunk, ignored otherwise -- t_off / t_len
                                        are right either way.  bioalign_batch lays its results out like this
                                        whenever it can: what crosses PCIe is then the traces, not their slots. */
-    BIOALIGN_TRACE_OPS = 1u << 2    /* instead of the two gapped strings, t1 receives one compact record per pair (t2
+    BIOALIGN_TRACE_OPS = 1u << 2,   /* instead of the two gapped strings, t1 receives one compact record per pair (t2
                                        is not touched and may be NULL): uint32 i, uint32 j -- the cell the alignment
-                                       ends in -- then the moves of the traceback, 2 bits each (0: s1[i-1] against a
+                                       ends in ((0, 0) when it has no moves) -- then the moves of the traceback, 2 bits each (0: s1[i-1] against a
                                        gap, i -= 1; 1: a gap against s2[j-1], j -= 1; 2: s1[i-1] against s2[j-1], both
                                        -= 1), first move = LAST column of the alignment, 16 moves per little-endian
                                        uint32.  t_off[p] = byte offset of the pair's record in t1, t_len[p] = number
                                        of moves.  t1 needs bioalign_ops_capacity() bytes.  bioalign_expand_ops() turns
                                        a record into the reference's two strings.  Linear gaps, batches that run in
                                        one workspace chunk; anything else answers BIOALIGN_EUNSUPPORTED. */
+    BIOALIGN_END_CELLS = 1u << 3    /* with BIOALIGN_SCORE_ONLY: no traceback, but t_off[p] = row i and t_len[p] =
+                                       column j of the cell the alignment ends in (global: (n, m); fitting /
+                                       overlap: (n, leftmost best column of the bottom row), align_pair.go:169-182;
+                                       local: the first best cell in row-major order, (0, 0) for score 0) -- e.g. the
+                                       length of the overlap for an assembler.  t1 / t2 are not touched.  Batch
+                                       kernels only (bioalign_long ignores it). */
 };
 
 /* error codes */

@@ -175,3 +175,47 @@ def test_compact_trace_records(mode):
     # affine gaps have no move records
     with pytest.raises(_native.BioAlignError):
         eng.batch(_native.PackedBatch(s1, o1, s2, o2, mode, table, c1, c2, 3, 1, flags=_native.TRACE_OPS))
+
+
+@pytest.mark.parametrize("mode", ["global", "local", "fitting", "overlap"])
+@pytest.mark.parametrize("affine", [False, True])
+def test_end_cells_without_traceback(mode, affine):
+    """BIOALIGN_SCORE_ONLY | BIOALIGN_END_CELLS: t_off / t_len = row / column of the cell the alignment ends in.
+    Checked against the traces of the ordinary run (themselves bit-exact against the oracle elsewhere): the
+    symbols of each trace are the stretch of its sequence that ends there; linear gaps: also the record headers
+    of BIOALIGN_TRACE_OPS."""
+    s1, o1, s2, o2 = _ragged(700, 31 + int(affine))
+    table, c1, c2 = synth.dna_table(1, -1)
+    go, ge = (3, 1) if affine else (1, 1)
+    eng = _native.Engine([0])
+    full = _traces(eng.batch(_native.PackedBatch(s1, o1, s2, o2, mode, table, c1, c2, go, ge)))
+    sc, _, _, ei, ej = eng.batch(_native.PackedBatch(s1, o1, s2, o2, mode, table, c1, c2, go, ge,
+                                                      flags=_native.SCORE_ONLY | _native.END_CELLS))
+    for p, (score, t1, t2) in enumerate(full):
+        x = s1[int(o1[p]):int(o1[p + 1])].tobytes()
+        y = s2[int(o2[p]):int(o2[p + 1])].tobytes()
+        i, j = int(ei[p]), int(ej[p])
+        a, b = t1.replace(b"-", b""), t2.replace(b"-", b"")
+        assert int(sc[p]) == score
+        assert 0 <= i <= len(x) and 0 <= j <= len(y), (p, i, j)
+        assert x[i - len(a):i] == a and y[j - len(b):j] == b, (mode, p, i, j, x, y, t1, t2)
+        if mode == "global":
+            assert (i, j) == (len(x), len(y))
+        if mode in ("fitting", "overlap"):
+            assert i == len(x)
+    if not affine:
+        _, r1, _, roff, rlen = eng.batch(_native.PackedBatch(s1, o1, s2, o2, mode, table, c1, c2, go, ge, flags=_native.TRACE_OPS))
+        words = r1[:len(r1) // 4 * 4].view(np.uint32)
+        idx = (roff // 4).astype(np.int64)
+        some = rlen > 0  # (a record without moves carries (0, 0))
+        assert some.any()
+        assert np.array_equal(words[idx].astype(np.uint64)[some], ei[some]) and np.array_equal(words[idx + 1].astype(np.uint64)[some], ej[some])
+    # the flag needs its two arrays
+    with pytest.raises(_native.BioAlignError):
+        pb = _native.PackedBatch(s1, o1, s2, o2, mode, table, c1, c2, go, ge, flags=_native.SCORE_ONLY | _native.END_CELLS)
+        r = _native.Result()
+        scores = np.zeros(700, dtype=np.int64)
+        r.scores = scores.ctypes.data
+        rc = _native.lib().bioalign_batch(eng._h, _native.C.byref(pb.c), _native.C.byref(r))
+        if rc != 0:
+            eng._raise(rc)
