@@ -55,6 +55,7 @@ EXPORTS = (
     "bioalign_fasta_copy_seq",
     "bioalign_all_pairs",
     "bioalign_all_pairs_range",
+    "bioalign_all_ordered_pairs",
     "bioalign_fasta_all_pairs",
     "bioalign_stripe_create",
     "bioalign_stripe_destroy",
@@ -171,6 +172,8 @@ def lib():
         L.bioalign_all_pairs.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
         L.bioalign_all_pairs_range.restype = C.c_int
         L.bioalign_all_pairs_range.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_uint64, C.c_uint64, C.c_void_p]
+        L.bioalign_all_ordered_pairs.restype = C.c_int
+        L.bioalign_all_ordered_pairs.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p]
         L.bioalign_fasta_all_pairs.restype = C.c_int
         L.bioalign_fasta_all_pairs.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
         L.bioalign_stripe_create.restype = C.c_void_p
@@ -331,6 +334,20 @@ class Engine:
         if rc != 0:
             self._raise(rc)
         return scores[:end - first]
+
+    def all_ordered_pairs(self, pb: PackedBatch, end_cells: bool = True):
+        """bioalign_all_ordered_pairs over the list `pb` describes (its s1 side) -> (scores, end_i, end_j), pair
+        number i*(n-1) + (j if j < i else j-1); end_i / end_j are None without end_cells."""
+        n = pb.n_pairs
+        total = n * (n - 1)
+        scores = np.zeros(max(total, 1), dtype=np.int64)
+        ei = np.zeros(max(total, 1), dtype=np.uint64) if end_cells else None
+        ej = np.zeros(max(total, 1), dtype=np.uint64) if end_cells else None
+        rc = lib().bioalign_all_ordered_pairs(self._h, C.byref(pb.c), scores.ctypes.data,
+                                              ei.ctypes.data if end_cells else None, ej.ctypes.data if end_cells else None)
+        if rc != 0:
+            self._raise(rc)
+        return scores[:total], (ei[:total] if end_cells else None), (ej[:total] if end_cells else None)
 
     def plan(self, pb: PackedBatch, device_index: int = 0) -> "Plan":
         return Plan(self, pb, device_index)

@@ -2,9 +2,9 @@
 
 The reference's AlignLong (align_long.go:17-90) finds overlaps by exact substring search -- the last half of s must
 occur in t verbatim (align_long.go:35-45) -- so one read error breaks the assembly.  AlignLongOverlap keeps the
-reference's greedy merge (steps 2-4, align_long.go:46-89) statement by statement and replaces step 1 by ONE batch of
-"overlap" alignments (suffix of s against prefix of t, align_pair.go:184-195) over all ordered pairs of fragments
-on the GPU.  Only scores and end cells come back (BIOALIGN_SCORE_ONLY | BIOALIGN_END_CELLS: the end cell's column is
+reference's greedy merge (steps 2-4, align_long.go:46-89) statement by statement and replaces step 1 by ONE call
+(bioalign_all_ordered_pairs) that aligns every ordered pair of fragments in "overlap" mode (suffix of s against
+prefix of t, align_pair.go:184-195) on the GPU, the fragments lying in HBM once.  Only scores and end cells come back (BIOALIGN_SCORE_ONLY | BIOALIGN_END_CELLS: the end cell's column is
 the length of t's prefix inside the overlap); there is no traceback at all.
 
 This changes behaviour on purpose (an overlap may contain mismatches and gaps), which is why SURVEY ranks it last.
@@ -20,16 +20,23 @@ from .subst_matrix import MatchAligner, score_table
 
 def overlap_end_cells(ss, pairs, a, indelPenalty: int):
     """Overlap alignments of (ss[si], ss[ti]) for every (si, ti) in pairs -> (scores, j_end): int64 arrays; j_end =
-    length of the prefix of ss[ti] that the alignment covers (column of the end cell, align_pair.go:169-182)."""
+    length of the prefix of ss[ti] that the alignment covers (column of the end cell, align_pair.go:169-182).
+
+    One call of bioalign_all_ordered_pairs: the fragments lie in HBM once, all n(n-1) ordered pairs are aligned
+    (score and end cell only, no traceback) and the pairs asked for are picked from the result."""
     from .align import _gap, engine, pack_sequences
 
-    d1, o1 = pack_sequences([ss[si] for si, _ in pairs])
-    d2, o2 = pack_sequences([ss[ti] for _, ti in pairs])
-    table, code1, code2 = score_table(a, np.unique(d1).tolist(), np.unique(d2).tolist())
-    pb = _native.PackedBatch(d1, o1, d2, o2, "overlap", table, code1, code2, indelPenalty, indelPenalty,
-                             gap_symbol=_gap(), flags=_native.SCORE_ONLY | _native.END_CELLS)
-    scores, _, _, _, j_end = engine().batch(pb)  # t_len = column of the end cell (include/bioalign.h)
-    return np.asarray(scores, dtype=np.int64), j_end.astype(np.int64)
+    n = len(ss)
+    data, off = pack_sequences(ss)
+    syms = np.unique(data).tolist()
+    table, code1, code2 = score_table(a, syms, syms)
+    pb = _native.PackedBatch(data, off, np.zeros(0, np.uint8), off, "overlap", table, code1, code2, indelPenalty,
+                             indelPenalty, gap_symbol=_gap(), flags=_native.SCORE_ONLY | _native.END_CELLS)
+    scores, _, j_end = engine().all_ordered_pairs(pb)
+    si = np.fromiter((p[0] for p in pairs), dtype=np.int64, count=len(pairs))
+    ti = np.fromiter((p[1] for p in pairs), dtype=np.int64, count=len(pairs))
+    idx = si * (n - 1) + np.where(ti < si, ti, ti - 1)
+    return scores[idx].astype(np.int64), j_end[idx].astype(np.int64)
 
 
 def AlignLongOverlap(ss, a=None, indelPenalty: int = 2, minScorePerColumn: float = 0.8, end_cells=None) -> bytes:

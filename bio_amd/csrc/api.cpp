@@ -1912,18 +1912,25 @@ void pair_of(uint64_t p, uint64_t *i, uint64_t *j)
     *j = p - r * (r - 1) / 2;
 }
 
-extern "C" hipError_t ba_launch_pair_offsets(const uint64_t *off, uint64_t c0, uint64_t n, uint64_t *q1, uint64_t *q2,
-                                             hipStream_t st);
+extern "C" hipError_t ba_launch_pair_offsets(const uint64_t *off, uint64_t c0, uint64_t n, uint64_t n_seqs, int ordered,
+                                             uint64_t *q1, uint64_t *q2, hipStream_t st);
+
+// what bioalign_all_pairs / bioalign_all_ordered_pairs enumerate, and where the results go
+struct PairSpace {
+    bool ordered = false;          // every (i, j) with i != j instead of j < i
+    int64_t *scores = nullptr;     // [0] is pair `base` of the numbering
+    uint64_t *end_i = nullptr, *end_j = nullptr;  // end cells (BIOALIGN_END_CELLS), or null
+    uint64_t base = 0;
+};
 
 // Pairs [lo, hi) on one device, in chunks of at most BIOALIGN_ALL_PAIRS_CHUNK pairs (one plan each).
 // d_list / d_off: the list's bytes and offsets if they already lie on this device, else null (h_list and off are
 // copied in).  The plan sees lengths only (virtual offsets); where each pair's sequences lie in the list is
 // computed on the device (ba_pair_offsets_kernel).
 int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in, const uint64_t *off,
-                    const uint8_t *h_list, const uint8_t *d_list, const uint64_t *d_off, int64_t *scores, uint64_t base,
-                    uint64_t lo, uint64_t hi, std::string *err)
+                    const uint8_t *h_list, const uint8_t *d_list, const uint64_t *d_off, const PairSpace &S, uint64_t lo,
+                    uint64_t hi, std::string *err)
 {
-    // (scores[0] is pair `base` of the numbering)
     bioalign_ctx local;  // (as run_share: concurrent shares do not race on the error string)
     local.devices = ctx->devices;
     local.pool = ctx->pool;
@@ -1934,8 +1941,9 @@ int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in
     hipStream_t st = nullptr;
     bioalign_plan *pl = nullptr;
     int rc = 0;
-    PoolBuf list, loff, q1, q2, sc;
+    PoolBuf list, loff, q1, q2, sc, e1, e2;
     std::vector<uint32_t> v1, v2;
+    const bool ends = S.end_i && S.end_j;
     const bool timing = env_u64("BIOALIGN_TIMING", 0) != 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) {
@@ -1967,15 +1975,30 @@ int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in
         if ((rc = q1.alloc(&local, hip_dev, (cap + 1) * 8)) != 0 || (rc = q2.alloc(&local, hip_dev, (cap + 1) * 8)) != 0 ||
             (rc = sc.alloc(&local, hip_dev, cap * 8)) != 0)
             goto done;
+        if (ends && ((rc = e1.alloc(&local, hip_dev, cap * 8)) != 0 || (rc = e2.alloc(&local, hip_dev, cap * 8)) != 0)) goto done;
         v1.resize(cap);
         v2.resize(cap);
     }
     for (uint64_t c0 = lo; c0 < hi; c0 += CH) {
         const uint64_t N = std::min(CH, hi - c0);
-        AP_TRY(ba_launch_pair_offsets(d_off, c0, N, q1.as<uint64_t>(), q2.as<uint64_t>(), st));
+        AP_TRY(ba_launch_pair_offsets(d_off, c0, N, n_seqs, S.ordered ? 1 : 0, q1.as<uint64_t>(), q2.as<uint64_t>(), st));
         uint64_t i, j;
-        pair_of(c0, &i, &j);
-        for (uint64_t k = 0; k < N;) {  // row i: its own length against the lengths of sequences j .. i - 1
+        if (S.ordered) {
+            i = c0 / (n_seqs - 1);
+            uint64_t r = c0 % (n_seqs - 1);
+            for (uint64_t k = 0; k < N; ++k) {
+                j = r < i ? r : r + 1;
+                v1[k] = (uint32_t)std::min<uint64_t>(off[i + 1] - off[i], 0xffffffffu);
+                v2[k] = (uint32_t)std::min<uint64_t>(off[j + 1] - off[j], 0xffffffffu);
+                if (++r == n_seqs - 1) {
+                    r = 0;
+                    ++i;
+                }
+            }
+        } else {
+            pair_of(c0, &i, &j);
+        }
+        for (uint64_t k = 0; !S.ordered && k < N;) {  // row i: its own length against the lengths of sequences j .. i - 1
             const uint32_t li = (uint32_t)std::min<uint64_t>(off[i + 1] - off[i], 0xffffffffu);
             const uint64_t stop = std::min<uint64_t>(N, k + (i - j));
             for (; k < stop; ++k, ++j) {
@@ -1993,7 +2016,7 @@ int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in
         sub.s1 = sub.s2 = nullptr;
         sub.s1_off = sub.s2_off = nullptr;
         sub.n_pairs = N;
-        sub.flags = BIOALIGN_SCORE_ONLY;
+        sub.flags = BIOALIGN_SCORE_ONLY | (ends ? BIOALIGN_END_CELLS : 0u);
         pl = new bioalign_plan;
         pl->ctx = &local;
         pl->device = dev_index;
@@ -2005,9 +2028,13 @@ int all_pairs_share(bioalign_ctx *ctx, int dev_index, const bioalign_batch_t *in
         t_plan += ms_since(t_mark);
         t_mark = now();
         rc = bioalign_plan_run(pl, d_list, q1.as<uint64_t>(), d_list, q2.as<uint64_t>(), sc.as<int64_t>(), nullptr,
-                               nullptr, nullptr, nullptr, st);
+                               nullptr, e1.as<uint64_t>(), e2.as<uint64_t>(), st);
         if (rc) goto done;
-        AP_TRY(hipMemcpyAsync(scores + (c0 - base), sc.p, N * 8, hipMemcpyDeviceToHost, st));
+        AP_TRY(hipMemcpyAsync(S.scores + (c0 - S.base), sc.p, N * 8, hipMemcpyDeviceToHost, st));
+        if (ends) {
+            AP_TRY(hipMemcpyAsync(S.end_i + (c0 - S.base), e1.p, N * 8, hipMemcpyDeviceToHost, st));
+            AP_TRY(hipMemcpyAsync(S.end_j + (c0 - S.base), e2.p, N * 8, hipMemcpyDeviceToHost, st));
+        }
         AP_TRY(hipStreamSynchronize(st));
         bioalign_plan_destroy(pl);
         pl = nullptr;
@@ -2026,14 +2053,15 @@ done:
 #undef AP_TRY
 }
 
-// pairs [first, first + count) of the triangle; scores[0] is pair `first`
+// pairs [first, first + count) of the numbering; S.scores[0] is pair `first`
 int all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, const uint64_t *off, const uint8_t *h_list,
-              const uint8_t *d_list, const uint64_t *d_off, int d_list_dev, uint64_t first, uint64_t count,
-              int64_t *scores)
+              const uint8_t *d_list, const uint64_t *d_off, int d_list_dev, uint64_t first, uint64_t count, PairSpace S)
 {
     const uint64_t n = in->n_pairs;
+    int64_t *const scores = S.scores;
+    S.base = first;
     if (n > (1ull << 31)) return ctx->fail(BIOALIGN_EINVAL, "too many sequences");
-    const uint64_t P = n < 2 ? 0 : n * (n - 1) / 2;
+    const uint64_t P = n < 2 ? 0 : (S.ordered ? n * (n - 1) : n * (n - 1) / 2);
     if (count == ~0ull) count = P - std::min(first, P);
     if (first > P || count > P - first) return ctx->fail(BIOALIGN_EINVAL, "pair range outside the triangle of %llu pairs", (unsigned long long)P);
     if (count == 0) return 0;
@@ -2049,8 +2077,8 @@ int all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, const uint64_t *off
     const int D = ndev * per_dev;
     std::vector<uint64_t> cut(D + 1, first + count);
     cut[0] = first;
-    if (D > 1 && count != P) {
-        for (int d = 1; d < D; ++d) cut[d] = first + count * d / D;  // a caller's range: by pair count
+    if (D > 1 && (count != P || S.ordered)) {
+        for (int d = 1; d < D; ++d) cut[d] = first + count * d / D;  // a caller's range, ordered pairs: by pair count
     } else if (D > 1) {
         // row i costs (len_i + 1) * sum over j < i of (len_j + 1)
         std::vector<double> cum(n + 1, 0.0), rowpre(n + 1, 0.0);
@@ -2072,8 +2100,8 @@ int all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, const uint64_t *off
     std::vector<int> rcs(D, 0);
     std::vector<std::string> errs(D);
     auto share = [&](int d) {
-        rcs[d] = all_pairs_share(ctx, d_list ? d_list_dev : d / per_dev, in, off, h_list, d_list, d_off, scores, first,
-                                 cut[d], cut[d + 1], &errs[d]);
+        rcs[d] = all_pairs_share(ctx, d_list ? d_list_dev : d / per_dev, in, off, h_list, d_list, d_off, S, cut[d],
+                                 cut[d + 1], &errs[d]);
     };
     if (D == 1) {
         share(0);
@@ -2098,7 +2126,24 @@ extern "C" int bioalign_all_pairs_range(bioalign_ctx *ctx, const bioalign_batch_
     if (!ctx) return BIOALIGN_EINVAL;
     if (!in || !in->s1_off) return ctx->fail(BIOALIGN_EINVAL, "null argument");
     if (in->s1_off[in->n_pairs] && !in->s1) return ctx->fail(BIOALIGN_EINVAL, "null sequence bytes");
-    return all_pairs(ctx, in, in->s1_off, in->s1, nullptr, nullptr, 0, first_pair, n_range, scores);
+    PairSpace S;
+    S.scores = scores;
+    return all_pairs(ctx, in, in->s1_off, in->s1, nullptr, nullptr, 0, first_pair, n_range, S);
+}
+
+extern "C" int bioalign_all_ordered_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, int64_t *scores, uint64_t *end_i,
+                                          uint64_t *end_j)
+{
+    if (!ctx) return BIOALIGN_EINVAL;
+    if (!in || !in->s1_off) return ctx->fail(BIOALIGN_EINVAL, "null argument");
+    if (in->s1_off[in->n_pairs] && !in->s1) return ctx->fail(BIOALIGN_EINVAL, "null sequence bytes");
+    if ((end_i == nullptr) != (end_j == nullptr)) return ctx->fail(BIOALIGN_EINVAL, "end_i and end_j come together");
+    PairSpace S;
+    S.ordered = true;
+    S.scores = scores;
+    S.end_i = end_i;
+    S.end_j = end_j;
+    return all_pairs(ctx, in, in->s1_off, in->s1, nullptr, nullptr, 0, 0, ~0ull, S);
 }
 
 extern "C" int bioalign_all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, int64_t *scores)
@@ -2113,5 +2158,7 @@ extern "C" int bioalign_fasta_all_pairs(const bioalign_fasta *F, const bioalign_
     if (!in) return ctx->fail(BIOALIGN_EINVAL, "null argument");
     bioalign_batch_t sub = *in;
     sub.n_pairs = F->n_records;
-    return all_pairs(ctx, &sub, F->h_off.data(), nullptr, F->seq.as<uint8_t>(), F->off.as<uint64_t>(), F->dev, 0, ~0ull, scores);
+    PairSpace S;
+    S.scores = scores;
+    return all_pairs(ctx, &sub, F->h_off.data(), nullptr, F->seq.as<uint8_t>(), F->off.as<uint64_t>(), F->dev, 0, ~0ull, S);
 }

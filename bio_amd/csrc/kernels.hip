@@ -967,14 +967,22 @@ extern "C" hipError_t ba_launch_trace_linear(const BaTraceParams &P, int mode, i
 
 // ----------------------------------------------------------------------------
 // All pairs of one list (bioalign_all_pairs): where the two sequences of pair c0 + k lie in the list.
-// Pair p = i(i-1)/2 + j, j < i, row by row; q1[k] = off[i] (row sequence), q2[k] = off[j] (column sequence).
+// Pair p = i(i-1)/2 + j, j < i, row by row (or every ordered pair i != j); q1[k] = off[i] (row sequence),
+// q2[k] = off[j] (column sequence).
 // ----------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) ba_pair_offsets_kernel(const uint64_t *__restrict__ off, uint64_t c0, uint64_t n,
-                                                              uint64_t *__restrict__ q1, uint64_t *__restrict__ q2)
+                                                              uint64_t n_seqs, int ordered, uint64_t *__restrict__ q1,
+                                                              uint64_t *__restrict__ q2)
 {
     const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     const uint64_t p = c0 + k;
+    if (ordered) {  // every (i, j), i != j, row by row: p = i (n_seqs - 1) + r, j = r skipping i
+        const uint64_t i = p / (n_seqs - 1), r = p % (n_seqs - 1);
+        q1[k] = off[i];
+        q2[k] = off[r < i ? r : r + 1];
+        return;
+    }
     // the row from the square root, then exact in integers (p < 2^62: the double is off by at most a few rows)
     uint64_t r = (uint64_t)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
     if (r < 1) r = 1;
@@ -984,11 +992,12 @@ __global__ void __launch_bounds__(256) ba_pair_offsets_kernel(const uint64_t *__
     q2[k] = off[p - r * (r - 1) / 2];
 }
 
-extern "C" hipError_t ba_launch_pair_offsets(const uint64_t *off, uint64_t c0, uint64_t n, uint64_t *q1, uint64_t *q2,
-                                             hipStream_t st)
+extern "C" hipError_t ba_launch_pair_offsets(const uint64_t *off, uint64_t c0, uint64_t n, uint64_t n_seqs, int ordered,
+                                             uint64_t *q1, uint64_t *q2, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(ba_pair_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, off, c0, n, q1, q2);
+    hipLaunchKernelGGL(ba_pair_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, off, c0, n, n_seqs,
+                       ordered, q1, q2);
     return hipGetLastError();
 }
 

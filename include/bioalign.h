@@ -304,6 +304,13 @@ int bioalign_all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, int64_t *s
 int bioalign_all_pairs_range(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t first_pair, uint64_t n_range,
                              int64_t *scores);
 int bioalign_fasta_all_pairs(const bioalign_fasta *fasta, const bioalign_batch_t *in, int64_t *scores);
+/* Every ORDERED pair (i, j), i != j, of the same list -- n(n-1) alignments, pair number i*(n-1) + (j < i ? j : j-1) --
+ * for modes that are not symmetric in their two sequences: the all-pairs step of a greedy assembler
+ * (align_long.go:35-45) asks for the "overlap" alignment of every fragment's suffix with every other fragment's
+ * prefix.  scores as above; end_i / end_j (both or neither; n(n-1) entries each) receive the end cell of every
+ * alignment as BIOALIGN_END_CELLS describes it: for "overlap", end_j is the length of the overlap in sequence j. */
+int bioalign_all_ordered_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, int64_t *scores, uint64_t *end_i,
+                               uint64_t *end_j);
 
 /*
  * Timing hooks for the benchmark (no counterpart in the reference): the plan

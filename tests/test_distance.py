@@ -111,3 +111,41 @@ def test_all_pairs_in_chunks_and_from_fasta(monkeypatch):
     back = {(n - 1 - i, n - 1 - j): v for i, j, v in zip(ii.tolist(), jj.tolist(), rev.tolist())}
     for i, j, v in zip(ii.tolist(), jj.tolist(), whole.tolist()):
         assert back[(j, i)] == v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["overlap", "fitting", "local"])
+def test_all_ordered_pairs_with_end_cells(mode, monkeypatch):
+    # every (i, j), i != j: scores against the oracle, end cells against the traces' extent
+    import bio_amd
+    from bio_amd import _native, pack_sequences, score_table
+
+    rng = np.random.default_rng(17)
+    l = _random_list(rng, 23, 0, 60)
+    n = len(l)
+    data, off = pack_sequences(l)
+    tbl, c1, c2 = score_table(bio_amd.MatchAligner(1, -1), np.unique(data).tolist(), np.unique(data).tolist())
+    pb = _native.PackedBatch(data, off, np.zeros(0, np.uint8), off, mode, tbl, c1, c2, 2, 2)
+    eng = bio_amd.engine()
+    sc, ei, ej = eng.all_ordered_pairs(pb)
+    monkeypatch.setenv("BIOALIGN_ALL_PAIRS_CHUNK", "100")
+    sc2, ei2, ej2 = eng.all_ordered_pairs(pb)
+    assert np.array_equal(sc, sc2) and np.array_equal(ei, ei2) and np.array_equal(ej, ej2)
+    assert len(sc) == n * (n - 1)
+    oa = O.MatchAligner(1, -1)
+    p = 0
+    for i in range(n):
+        for j in range(n):
+            if i == j:
+                continue
+            score, t1, t2 = O.AlignPair(mode, l[i], l[j], oa, 2)
+            a = (t1 or b"").replace(b"-", b"")
+            b = (t2 or b"").replace(b"-", b"")
+            e_i, e_j = int(ei[p]), int(ej[p])
+            assert int(sc[p]) == score, (mode, i, j)
+            assert l[i][e_i - len(a):e_i] == a and l[j][e_j - len(b):e_j] == b, (mode, i, j, e_i, e_j)
+            if mode != "local":
+                assert e_i == len(l[i])
+            p += 1
+    sc3, none_i, none_j = eng.all_ordered_pairs(pb, end_cells=False)
+    assert none_i is None and none_j is None and np.array_equal(sc3, sc)
