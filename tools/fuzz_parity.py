@@ -134,11 +134,12 @@ def main():
         if affine and ext == gap:
             affine = False
         mode = MODES[int(rng.integers(0, 4))]
-        form = rng.choice(["strings", "ops", "scores"]) if not affine else rng.choice(["strings", "scores"])
+        form = rng.choice(["strings", "ops", "scores", "ends"]) if not affine else rng.choice(["strings", "scores", "ends"])
         d1, o1 = pack_sequences(s1s)
         d2, o2 = pack_sequences(s2s)
         tbl, c1, c2 = score_table(pa, np.unique(d1).tolist(), np.unique(d2).tolist())
-        flags = {"strings": 0, "ops": _native.TRACE_OPS, "scores": _native.SCORE_ONLY}[form]
+        flags = {"strings": 0, "ops": _native.TRACE_OPS, "scores": _native.SCORE_ONLY,
+                 "ends": _native.SCORE_ONLY | _native.END_CELLS}[form]
         pb = _native.PackedBatch(d1, o1, d2, o2, mode, tbl, c1, c2, gap, ext, flags=flags)
         try:
             scores, t1, t2, t_off, t_len = eng.batch(pb)
@@ -150,7 +151,14 @@ def main():
         for p, (x, y) in enumerate(zip(s1s, s2s)):
             want = O.AlignAffine(mode, x, y, oa, gap, ext) if affine else O.AlignPair(mode, x, y, oa, gap)
             ok = int(scores[p]) == want[0]
-            if ok and form != "scores":
+            if ok and form == "ends":
+                # the end cell: the symbols of each trace are the stretch of its sequence that ends there
+                i, j = int(t_off[p]), int(t_len[p])
+                a, b = (want[1] or b"").replace(b"-", b""), (want[2] or b"").replace(b"-", b"")
+                ok = 0 <= i <= len(x) and 0 <= j <= len(y) and x[i - len(a):i] == a and y[j - len(b):j] == b
+                if mode != "local":
+                    ok = ok and i == len(x) and (mode != "global" or j == len(y))
+            elif ok and form != "scores":
                 o, ln = int(t_off[p]), int(t_len[p])
                 if form == "ops":
                     g1, g2 = _native.expand_ops(x, y, t1, o, ln)
