@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--profile", default="default", choices=sorted(SIZES), help="batch sizes and lengths to draw from")
+    ap.add_argument("--fasta", action="store_true", help="the FASTA parser (both readers' rules) on random texts")
     ap.add_argument("--long", action="store_true", help="long mode (bioalign_long) on single pairs instead of batches")
     ap.add_argument("--stripes", type=int, default=0, help="with --long: force this many column stripes")
     args = ap.parse_args()
@@ -88,6 +89,57 @@ def main():
     t_end = time.time() + args.seconds
     global PROFILE
     PROFILE = args.profile
+    if args.fasta:
+        pieces = [b">", b">h d", b"ACGT", b"A C", b" ", b"\r", b"\n", b"\n", b"\r\n", b"\n\n", b"N" * 40, b"\t", b"ACGTACGTAC" * 15 + b"\n",
+                  b"G" * 59 + b"\n", b">read/1 length=150\n"]
+        k = 0
+        while time.time() < t_end:
+            size = int(rng.choice([0, 5, 60, 3000, 20000, 70000]))
+            text = b"".join(pieces[int(rng.integers(0, len(pieces)))] for _ in range(size))
+            if rng.integers(0, 4) == 0 and text:
+                text = b">first\n" + text
+            # ReadFASTA's rules (fasta.go:55-84)
+            try:
+                want = O.ReadFASTA(text)
+            except ValueError as e:
+                want = str(e)
+            try:
+                got = [(f.Header.encode("latin-1"), f.Seq) for f in bio_amd.ReadFASTA(text)]
+            except ValueError as e:
+                got = str(e)
+            if got != want:
+                print("MISMATCH ReadFASTA", dict(text=text[:2000]), flush=True)
+                sys.exit(1)
+            # FASTAReader.ReadSeq's rules (fasta.go:93-142), three buffer sizes
+            for limit in (16, 200, 4096):
+                r = O.FASTAReader(text, limit)
+                want = []
+                while True:
+                    h, sq, err = r.ReadSeq()
+                    if err is not None:
+                        want.append(err)
+                        break
+                    want.append((h, sq))
+                g = bio_amd.NewFASTAReader(text, limit)
+                got = []
+                while True:
+                    try:
+                        f = g.ReadSeq()
+                    except EOFError:
+                        got.append("EOF")
+                        break
+                    except ValueError as e:
+                        got.append(str(e))
+                        break
+                    got.append((f.Header.encode("latin-1"), f.Seq))
+                if got != want:
+                    print("MISMATCH FASTAReader", dict(limit=limit, text=text[:2000]), flush=True)
+                    sys.exit(1)
+            k += 1
+            if k % 50 == 0:
+                print(f"{k} texts, both readers, all equal", flush=True)
+        print(f"done: {k} FASTA texts, both readers (buffers 16 / 200 / 4096), all equal (seed {args.seed})", flush=True)
+        return
     if args.long:
         if args.stripes:
             os.environ["BIOALIGN_LONG_STRIPES"] = str(args.stripes)
