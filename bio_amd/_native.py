@@ -38,6 +38,7 @@ EXPORTS = (
     "bioalign_plan_run",
     "bioalign_plan_share_pack",
     "bioalign_plan_dp_ms",
+    "bioalign_run_noalloc",
     "bioalign_ops_capacity",
     "bioalign_expand_ops",
     "bioalign_fasta_parse",
@@ -188,6 +189,8 @@ def lib():
         L.bioalign_stripe_walk.restype = C.c_int
         L.bioalign_stripe_walk.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.bioalign_run_noalloc.restype = C.c_int
+        L.bioalign_run_noalloc.argtypes = [C.c_void_p, C.c_int, C.POINTER(Batch)] + [C.c_void_p] * 9 + [C.c_void_p]
         L.bioalign_plan_dp_ms.restype = C.c_int
         L.bioalign_plan_dp_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         _lib = L
@@ -348,6 +351,15 @@ class Engine:
         if rc != 0:
             self._raise(rc)
         return scores[:total], (ei[:total] if end_cells else None), (ej[:total] if end_cells else None)
+
+    def run_noalloc(self, pb: PackedBatch, d_s1, d_s1_off, d_s2, d_s2_off, d_scores, d_t1, d_t2, d_t_off, d_t_len,
+                    stream=0, device_index: int = 0):
+        """bioalign_run_noalloc: plan + run in one call on device-resident data (raw device addresses), the whole
+        workspace inside the library's fixed scratch array -- no allocation of any kind.  Returns when done."""
+        rc = lib().bioalign_run_noalloc(self._h, device_index, C.byref(pb.c), d_s1, d_s1_off, d_s2, d_s2_off, d_scores,
+                                        d_t1, d_t2, d_t_off, d_t_len, stream)
+        if rc != 0:
+            self._raise(rc)
 
     def plan(self, pb: PackedBatch, device_index: int = 0) -> "Plan":
         return Plan(self, pb, device_index)

@@ -122,8 +122,18 @@ struct DevPool {
     }
 };
 
+// Scratch of the allocation-free entry point (bioalign_run_noalloc, include/bioalign.h): the whole workspace of one
+// small batch -- bundle table, pair order, score tables, packed sequence words, boundary rows, residue / decision
+// words, move records, end cells -- lives in this file-scope device array instead of hipMalloc'ed memory.  Every
+// GPU the library's code object is loaded on holds its own copy at its own address until the process ends.  The
+// name is a host-side stand-in, NOT a device address: host code only ever uses the per-device pointer that
+// hipGetSymbolAddress returns (bioalign_create resolves it once per device of the context, with that device
+// current) -- as kernel arguments, like the hipMalloc'ed workspace of the other entry points.
+static __device__ __align__(256) unsigned char scratch[BIOALIGN_NOALLOC_SCRATCH_BYTES];
+
 struct bioalign_ctx {
     std::vector<int> devices;
+    std::vector<unsigned char *> scratch_ptr;  // per entry of `devices`: that GPU's address of `scratch`
     std::shared_ptr<DevPool> pool;  // bioalign_batch's device memory (see DevPool)
     std::string err;
     int code = 0;  // code of the last failure
@@ -198,6 +208,11 @@ struct bioalign_plan {
     hipEvent_t ev_side_done = nullptr;
     std::vector<void *> allocs;
     std::shared_ptr<DevPool> pool;  // set: the plan's memory comes from (and goes back to) bioalign_batch's pool
+    // bioalign_run_noalloc: the plan's device memory is carved out of this GPU's `scratch` array (no hipMalloc, no
+    // stream or event of the plan's own); uploads go on `arena_stream`, the caller's
+    unsigned char *arena = nullptr;
+    size_t arena_cap = 0, arena_used = 0;
+    hipStream_t arena_stream = nullptr;
 };
 
 namespace {
@@ -205,6 +220,18 @@ namespace {
 int dev_alloc(bioalign_plan *pl, void **p, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
+    if (pl->arena) {
+        const size_t at = (pl->arena_used + 255) & ~(size_t)255;
+        if (at + bytes > pl->arena_cap)
+            return pl->ctx->fail(BIOALIGN_EUNSUPPORTED,
+                                 "bioalign_run_noalloc: this batch needs more than the %zu bytes of scratch the entry point "
+                                 "owns (BIOALIGN_NOALLOC_SCRATCH_BYTES); use bioalign_plan_create / bioalign_plan_run",
+                                 pl->arena_cap);
+        *p = pl->arena + at;
+        pl->arena_used = at + bytes;
+        pl->ws_bytes += bytes;
+        return 0;
+    }
     if (pl->pool) {
         *p = pl->pool->get(pl->ctx->devices[pl->device], bytes);
         if (!*p) return pl->ctx->fail(BIOALIGN_ENOMEM, "hipMalloc of %zu bytes failed", bytes);
@@ -262,6 +289,24 @@ extern "C" bioalign_ctx *bioalign_create(const int *device_ids, int n_devices)
             ctx->devices.push_back(device_ids[i]);
         }
     }
+    // this GPU's copy of the allocation-free entry point's scratch array: resolved once per device, with that
+    // device current (each GPU holds the array at its own address)
+    int prev_dev = 0;
+    (void)hipGetDevice(&prev_dev);
+    for (int d : ctx->devices) {
+        void *sp = nullptr;
+        e = hipSetDevice(d);
+        if (e == hipSuccess) e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !sp) {
+            g_create_error = std::string("hipGetSymbolAddress(scratch) failed on device ") + std::to_string(d) + ": " +
+                             hipGetErrorString(e);
+            (void)hipSetDevice(prev_dev);
+            delete ctx;
+            return nullptr;
+        }
+        ctx->scratch_ptr.push_back(static_cast<unsigned char *>(sp));
+    }
+    (void)hipSetDevice(prev_dev);
     ctx->pool = std::make_shared<DevPool>();
     ctx->pool->cap = env_u64("BIOALIGN_POOL_BYTES", 64ull << 30);
     return ctx;
@@ -441,6 +486,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
     }
     auto at = [&](uint64_t q) -> uint64_t { return uniform ? q : perm[q]; };
     uint64_t budget = env_u64("BIOALIGN_WORKSPACE_BYTES", 96ull << 30);
+    if (pl->arena) budget = ~0ull >> 1;  // one chunk; dev_alloc refuses what does not fit the scratch array
     pl->bundles.clear();
     pl->chunks.clear();
     uint64_t o_s1w = 0, o_s2w = 0, o_hb = 0, o_dir = 0, o_rec = 0;
@@ -585,8 +631,8 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
     {
         // on a stream of the plan's own that does not synchronise with the null stream: a plan that is built while
         // another range's kernels run (bioalign_batch, bioalign_all_pairs) does not wait for them
-        hipStream_t cs = nullptr;
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        hipStream_t cs = pl->arena_stream;  // (allocation-free entry point: the caller's stream, nothing is created)
+        if (!pl->arena) HIP_TRY(ctx, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         hipError_t e = hipSuccess;
         auto up = [&](void *dst, const void *src, size_t bytes) {
             if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs);
@@ -602,7 +648,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         up(pl->d_table, in->score_table, (size_t)pl->na * pl->nb * 4);
         up(pl->d_wt, wt.data(), wt.size() * 4);
         if (e == hipSuccess) e = hipStreamSynchronize(cs);  // (the sources are locals; runs come on the caller's streams)
-        (void)hipStreamDestroy(cs);
+        if (!pl->arena) (void)hipStreamDestroy(cs);
         if (e != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "plan upload failed: %s", hipGetErrorString(e));
     }
     // Large batches: cut every chunk into slices so that the (latency-bound) traceback of one slice
@@ -615,6 +661,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         const uint64_t want = env_u64("BIOALIGN_SLICES", 1);
         pl->slices = (!pl->score_only && biggest >= 4096 && want > 1) ? (int)std::min<uint64_t>(want, 16) : 1;
         if (pl->dense) pl->slices = 1;  // (the scan of the lengths sits between the walks and the expansion of the whole batch)
+        if (pl->arena) pl->slices = 1;  // (no side stream, no events: nothing is created)
         if (pl->slices > 1) {
             HIP_TRY(ctx, hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
             pl->ev_slice.resize(pl->slices);
@@ -623,7 +670,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         }
     }
     pb_d = pb_ms();
-    const size_t pool = 256;
+    const size_t pool = pl->arena ? 0 : 256;  // (allocation-free entry point: no timing events)
     pl->ev0.resize(pool);
     pl->ev1.resize(pool);
     for (size_t c = 0; c < pool; ++c) {
@@ -846,6 +893,37 @@ extern "C" int bioalign_plan_dp_ms(bioalign_plan *pl, float *ms, int *n_launches
     if (n_launches) *n_launches = (int)pl->ev_used;
     pl->ev_used = 0;
     return 0;
+}
+
+// The allocation-free variant of bioalign_plan_create + bioalign_plan_run (include/bioalign.h): the same planner and
+// the same kernels, with the plan's device memory carved out of this GPU's `scratch` array.  Calls no hipMalloc /
+// hipFree, creates no stream and no event; uploads its small tables on the caller's stream and returns when the
+// work queued on that stream is done (its host-side tables are locals).
+extern "C" int bioalign_run_noalloc(bioalign_ctx *ctx, int device_index, const bioalign_batch_t *in, const uint8_t *d_s1,
+                                    const uint64_t *d_s1_off, const uint8_t *d_s2, const uint64_t *d_s2_off,
+                                    int64_t *d_scores, uint8_t *d_t1, uint8_t *d_t2, uint64_t *d_t_off,
+                                    uint64_t *d_t_len, void *stream)
+{
+    if (!ctx) return BIOALIGN_EINVAL;
+    if (!in) return ctx->fail(BIOALIGN_EINVAL, "null batch");
+    if (device_index < 0 || device_index >= (int)ctx->devices.size())
+        return ctx->fail(BIOALIGN_EINVAL, "device index %d out of range", device_index);
+    if (in->n_pairs == 0) return 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->devices[device_index]));
+    bioalign_plan pl;  // (host object only; nothing of it outlives the call)
+    pl.ctx = ctx;
+    pl.device = device_index;
+    pl.arena = ctx->scratch_ptr[device_index];  // the pointer hipGetSymbolAddress gave for THIS device, never the array's name
+    pl.arena_cap = BIOALIGN_NOALLOC_SCRATCH_BYTES;
+    pl.arena_stream = (hipStream_t)stream;
+    int rc = plan_build(&pl, in);
+    if (rc == 0 && pl.chunks.size() > 1) rc = ctx->fail(BIOALIGN_EUNSUPPORTED, "bioalign_run_noalloc: the batch does not run in one chunk");
+    if (rc == 0)
+        rc = bioalign_plan_run(&pl, d_s1, d_s1_off, d_s2, d_s2_off, d_scores, d_t1, d_t2, d_t_off, d_t_len, stream);
+    // the kernels read the plan's tables from the scratch array: the next call on this GPU overwrites them
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (rc == 0 && e != hipSuccess) rc = ctx->fail(BIOALIGN_EHIP, "bioalign_run_noalloc: %s", hipGetErrorString(e));
+    return rc;
 }
 
 // One device's share of bioalign_batch: pairs [lo, hi) of the caller's batch.

@@ -313,6 +313,28 @@ int bioalign_all_ordered_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, in
                                uint64_t *end_j);
 
 /*
+ * One entry point that allocates nothing.  It has no counterpart in the reference; it is for callers that cannot
+ * call hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  It is
+ * bioalign_plan_create + bioalign_plan_run + bioalign_plan_destroy in one call -- same arguments (`in` as for
+ * bioalign_plan_create: host offsets give the lengths, in->s1 / s2 may be NULL; the d_ pointers as for
+ * bioalign_plan_run: device memory on device `device_index` of the context), same planner, same kernels, same
+ * results -- except that the plan's whole device workspace (bundle table, packed sequence words, boundary rows,
+ * residue / decision words, move records, end cells) lies in a fixed array of BIOALIGN_NOALLOC_SCRATCH_BYTES
+ * that the library's code object holds on every GPU it is loaded on until the process ends.  The call makes no
+ * hipMalloc / hipFree, creates no stream or event, uploads its few KB of tables on `stream` and returns once the
+ * work queued on `stream` is done.  A batch whose workspace does not fit the array (about 10 000 pairs of 150 bp
+ * with linear gaps, 2 bits per cell; half that many cells with affine gaps) answers BIOALIGN_EUNSUPPORTED and
+ * nothing is run; BIOALIGN_DENSE_TRACES / BIOALIGN_TRACE_OPS / BIOALIGN_SCORE_ONLY / BIOALIGN_END_CELLS work as in
+ * plans.  Every call on a GPU shares that GPU's array, which keeps the last call's contents (the kernels write
+ * every word before they read it, nothing has to start at zero): two calls that overlap on one GPU -- from two
+ * threads, contexts or streams -- race; calls on different GPUs do not.
+ */
+#define BIOALIGN_NOALLOC_SCRATCH_BYTES (64u << 20)
+int bioalign_run_noalloc(bioalign_ctx *ctx, int device_index, const bioalign_batch_t *in, const uint8_t *d_s1,
+                         const uint64_t *d_s1_off, const uint8_t *d_s2, const uint64_t *d_s2_off, int64_t *d_scores,
+                         uint8_t *d_t1, uint8_t *d_t2, uint64_t *d_t_off, uint64_t *d_t_len, void *stream);
+
+/*
  * Timing hooks for the benchmark (no counterpart in the reference): the plan
  * records a pair of HIP events around every DP kernel launch, on the launch
  * stream, into a fixed pool of 256 pairs.  Once the stream has been

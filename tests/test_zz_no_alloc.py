@@ -1,0 +1,100 @@
+"""The allocation-free entry point (bioalign_run_noalloc, include/bioalign.h): same results as the existing
+bioalign_plan_create + bioalign_plan_run on the same device-resident inputs, bit for bit (scores, trace offsets and
+lengths, both traces), on two calls in a row -- the second with a SMALLER input, so that whatever the first call
+left in the shared scratch array is stale for it -- in linear and affine modes; sizes beyond the scratch maximum are
+refused with a clear error and nothing is run."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bio_amd
+from bio_amd import _native, score_table, synth
+
+
+def _device_batch(s1, o1, s2, o2):
+    dev = torch.device("cuda", 0)
+    return [torch.from_numpy(np.array(x, copy=True)).to(dev) for x in (s1, o1.view(np.int64), s2, o2.view(np.int64))]
+
+
+def _outputs(n, cap, fill):
+    dev = torch.device("cuda", 0)
+    return dict(scores=torch.full((max(n, 1),), fill, dtype=torch.int64, device=dev),
+                t1=torch.full((cap + 16,), fill & 0x7f, dtype=torch.uint8, device=dev),
+                t2=torch.full((cap + 16,), fill & 0x7f, dtype=torch.uint8, device=dev),
+                t_off=torch.full((max(n, 1),), fill, dtype=torch.int64, device=dev),
+                t_len=torch.full((max(n, 1),), fill, dtype=torch.int64, device=dev))
+
+
+def _ptrs(d, o):
+    return (d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), o["scores"].data_ptr(), o["t1"].data_ptr(),
+            o["t2"].data_ptr(), o["t_off"].data_ptr(), o["t_len"].data_ptr())
+
+
+def _same(a, b, n, what):
+    torch.cuda.synchronize()
+    sa, sb = a["scores"][:n].cpu().numpy(), b["scores"][:n].cpu().numpy()
+    assert np.array_equal(sa, sb), f"{what}: scores differ"
+    oa, ob = a["t_off"][:n].cpu().numpy(), b["t_off"][:n].cpu().numpy()
+    la, lb = a["t_len"][:n].cpu().numpy(), b["t_len"][:n].cpu().numpy()
+    assert np.array_equal(oa, ob) and np.array_equal(la, lb), f"{what}: trace offsets / lengths differ"
+    t1a, t1b = a["t1"].cpu().numpy(), b["t1"].cpu().numpy()
+    t2a, t2b = a["t2"].cpu().numpy(), b["t2"].cpu().numpy()
+    for p in range(n):
+        o, l = int(oa[p]), int(la[p])
+        assert np.array_equal(t1a[o:o + l], t1b[o:o + l]) and np.array_equal(t2a[o:o + l], t2b[o:o + l]), f"{what}: traces differ at pair {p}"
+
+
+def _both_ways(eng, batch, mode, table, c1, c2, go, ge, what):
+    s1, o1, s2, o2 = batch
+    n = len(o1) - 1
+    pb = _native.PackedBatch(s1, o1, s2, o2, mode, table, c1, c2, go, ge)
+    d = _device_batch(s1, o1, s2, o2)
+    cap = pb.trace_capacity
+    ref, got = _outputs(n, cap, 0x55), _outputs(n, cap, 0x2a)
+    plan = eng.plan(pb)
+    stream = torch.cuda.current_stream().cuda_stream
+    plan.run(*_ptrs(d, ref), stream)
+    eng.run_noalloc(pb, *_ptrs(d, got), stream)
+    _same(ref, got, n, what)
+    plan.close()
+
+
+def test_noalloc_matches_plan_run_twice_second_call_smaller():
+    eng = bio_amd.align.engine()
+    table, c1, c2 = synth.dna_table(1, -1)
+    big = synth.dna_pairs(3000, 150, 150, config=2)
+    small = synth.dna_pairs(700, 97, 120, config=2, first=5000)
+    for mode in ("global", "local"):
+        _both_ways(eng, big, mode, table, c1, c2, 1, 1, f"{mode} 3000 x 150x150")
+        _both_ways(eng, small, mode, table, c1, c2, 1, 1, f"{mode} 700 x 97x120 (after the larger call)")
+    # affine, fitting: read against window, then a smaller batch of other shapes
+    _both_ways(eng, synth.fitting_reads(600, 100, 400, config=4), "fitting", table, c1, c2, 5, 1, "fitting affine 600")
+    _both_ways(eng, synth.fitting_reads(100, 60, 250, config=4, first=900), "overlap", table, c1, c2, 5, 1, "overlap affine 100")
+    # proteins, ragged shapes (every distinct shape is a bundle of its own, 64 lanes wide in the workspace)
+    rng = np.random.default_rng(3)
+    seqs1 = [bytes(rng.choice(synth.AA, size=int(rng.integers(0, 80))).tolist()) for _ in range(120)]
+    seqs2 = [bytes(rng.choice(synth.AA, size=int(rng.integers(0, 80))).tolist()) for _ in range(120)]
+    d1, o1 = bio_amd.pack_sequences(seqs1)
+    d2, o2 = bio_amd.pack_sequences(seqs2)
+    tb, k1, k2 = score_table(bio_amd.Blosum62, np.unique(d1).tolist(), np.unique(d2).tolist())
+    _both_ways(eng, (d1, o1, d2, o2), "local", tb, k1, k2, 11, 1, "ragged protein local affine")
+    _both_ways(eng, (d1[: int(o1[50])], o1[:51], d2[: int(o2[50])], o2[:51]), "global", tb, k1, k2, 5, 5, "ragged protein global linear")
+
+
+def test_noalloc_refuses_what_does_not_fit():
+    eng = bio_amd.align.engine()
+    table, c1, c2 = synth.dna_table(1, -1)
+    s1, o1, s2, o2 = synth.dna_pairs(40_000, 150, 150, config=2)  # ~250 MB of residue words
+    pb = _native.PackedBatch(s1, o1, s2, o2, "global", table, c1, c2, 1, 1)
+    d = _device_batch(s1, o1, s2, o2)
+    out = _outputs(40_000, pb.trace_capacity, 0x11)
+    with pytest.raises(_native.BioAlignError) as e:
+        eng.run_noalloc(pb, *_ptrs(d, out), torch.cuda.current_stream().cuda_stream)
+    assert e.value.code == _native.EUNSUPPORTED and "scratch" in str(e.value)
+    torch.cuda.synchronize()
+    assert int(out["scores"][0].item()) == 0x11  # nothing ran
+    # and the engine still works afterwards
+    small = synth.dna_pairs(64, 50, 50, config=2)
+    _both_ways(eng, small, "global", table, c1, c2, 1, 1, "after a refusal")
