@@ -1156,6 +1156,7 @@ extern "C" int bioalign_batch(bioalign_ctx *ctx, const bioalign_batch_t *in, bio
 // long mode: one pair at a time on the intra-sequence wavefront kernels (kernels_long.hip)
 // ----------------------------------------------------------------------------
 extern "C" int ba_long_rows_per_lane(int K);
+extern "C" int ba_long_strips_per_group(void);
 extern "C" hipError_t ba_launch_long(const BaLongParams &P, int mode, int T, int K, int phases, hipStream_t st);
 
 namespace {
@@ -1190,6 +1191,7 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     const int cpd = 32 / (T * K);
     const uint64_t rs = 64ull * T;
     const uint64_t strips = (n + rs - 1) / rs;
+    const uint64_t nsuper = (strips + ba_long_strips_per_group() - 1) / ba_long_strips_per_group();
     const uint64_t wps = (m + 63 + cpd - 1) / cpd;
 
     HIP_TRY(ctx, hipSetDevice(ctx->devices[0]));
@@ -1197,7 +1199,7 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     int rc;
     if ((rc = d_s1.alloc(ctx, n + 16)) || (rc = d_s2.alloc(ctx, m + 16)) || (rc = d_prof.alloc(ctx, rowprof.size() * 4)) ||
         (rc = d_c1.alloc(ctx, 256)) || (rc = d_c2.alloc(ctx, 256)) || (rc = d_tab.alloc(ctx, (size_t)in->na * in->nb * 4)) ||
-        (rc = d_bnd.alloc(ctx, strips * m * 4)) || (rc = d_flags.alloc(ctx, strips * 4 + 4)) ||
+        (rc = d_bnd.alloc(ctx, nsuper * ((m + 63) / 64 * 64) * 4 + 256)) || (rc = d_flags.alloc(ctx, nsuper * 4 + 4)) ||
         (rc = d_res.alloc(ctx, strips * wps * 256)) || (rc = d_misc.alloc(ctx, 64)))
         return rc;
     const uint64_t cap = n + m;
@@ -1211,10 +1213,12 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     HIP_TRY(ctx, hipMemcpyAsync(d_c1.p, in->code1, 256, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d_c2.p, in->code2, 256, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d_tab.p, in->score_table, (size_t)in->na * in->nb * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemsetAsync(d_flags.p, 0, strips * 4 + 4, st));
+    HIP_TRY(ctx, hipMemsetAsync(d_flags.p, 0, nsuper * 4 + 4, st));
     HIP_TRY(ctx, hipMemsetAsync(d_misc.p, 0, 64, st));
 
     BaLongParams P;
+    P.nsuper = (uint32_t)nsuper;
+    P.bnd_stride = (uint32_t)((m + 63) / 64 * 64);
     P.s1 = d_s1.as<uint8_t>();
     P.s2 = d_s2.as<uint8_t>();
     P.n = (uint32_t)n;
@@ -1248,6 +1252,7 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     P.start_i = 0;
     P.start_j = -1;
     P.scan_only = 0;
+    P.dbg = (int)env_u64("BIOALIGN_LONG_DBG", 0);
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(ctx, hipEventCreate(&e0));
@@ -1295,7 +1300,7 @@ struct bioalign_stripe {
     bioalign_ctx *ctx = nullptr;
     int dev = 0;          // index into ctx->devices
     int mode = 0, T = 8, K = 2;
-    uint64_t n = 0, c0 = 0, m = 0, m_total = 0, wps = 0, strips = 0;
+    uint64_t n = 0, c0 = 0, m = 0, m_total = 0, wps = 0, strips = 0, nsuper = 0;
     bool traces = true, dp_done = false;
     DevBuf s1, s2, prof, c1, c2, bnd, flags, res, misc, t1, t2, ops, left, right;
     hipStream_t st = nullptr;
@@ -1367,14 +1372,15 @@ int stripe_init(bioalign_stripe &x, bioalign_ctx *ctx, int dev, const bioalign_b
     const int cpd = 32 / (x.T * x.K);
     const uint64_t rs = 64ull * x.T;
     x.strips = (n + rs - 1) / rs;
+    x.nsuper = (x.strips + ba_long_strips_per_group() - 1) / ba_long_strips_per_group();
     x.wps = (x.m + 63 + cpd - 1) / cpd;
     HIP_TRY(ctx, hipSetDevice(ctx->devices[dev]));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&x.st, hipStreamNonBlocking));
     HIP_TRY(ctx, hipEventCreateWithFlags(&x.done, hipEventDisableTiming));
     const uint64_t cap = n + x.m;
     if ((rc = x.s1.alloc(ctx, n + 16)) || (rc = x.s2.alloc(ctx, x.m + 16)) || (rc = x.prof.alloc(ctx, rowprof.size() * 4)) ||
-        (rc = x.c1.alloc(ctx, 256)) || (rc = x.c2.alloc(ctx, 256)) || (rc = x.bnd.alloc(ctx, x.strips * x.m * 4)) ||
-        (rc = x.flags.alloc(ctx, x.strips * 4 + 4)) || (rc = x.res.alloc(ctx, x.strips * x.wps * 256)) ||
+        (rc = x.c1.alloc(ctx, 256)) || (rc = x.c2.alloc(ctx, 256)) || (rc = x.bnd.alloc(ctx, x.nsuper * ((x.m + 63) / 64 * 64) * 4 + 256)) ||
+        (rc = x.flags.alloc(ctx, x.nsuper * 4 + 4)) || (rc = x.res.alloc(ctx, x.strips * x.wps * 256)) ||
         (rc = x.misc.alloc(ctx, 64)) || (rc = x.left.alloc(ctx, (n + 1) * 4)) || (rc = x.right.alloc(ctx, (n + 1) * 4)))
         return rc;
     if (x.traces && ((rc = x.t1.alloc(ctx, cap + 32)) || (rc = x.t2.alloc(ctx, cap + 32)) ||
@@ -1385,7 +1391,7 @@ int stripe_init(bioalign_stripe &x, bioalign_ctx *ctx, int dev, const bioalign_b
     HIP_TRY(ctx, hipMemcpyAsync(x.prof.p, rowprof.data(), rowprof.size() * 4, hipMemcpyHostToDevice, x.st));
     HIP_TRY(ctx, hipMemcpyAsync(x.c1.p, in->code1, 256, hipMemcpyHostToDevice, x.st));
     HIP_TRY(ctx, hipMemcpyAsync(x.c2.p, in->code2, 256, hipMemcpyHostToDevice, x.st));
-    HIP_TRY(ctx, hipMemsetAsync(x.flags.p, 0, x.strips * 4 + 4, x.st));
+    HIP_TRY(ctx, hipMemsetAsync(x.flags.p, 0, x.nsuper * 4 + 4, x.st));
     HIP_TRY(ctx, hipMemsetAsync(x.misc.p, 0, 64, x.st));
     HIP_TRY(ctx, hipStreamSynchronize(x.st));  // rowprof is a local
     BaLongParams &P = x.P;
@@ -1394,6 +1400,8 @@ int stripe_init(bioalign_stripe &x, bioalign_ctx *ctx, int dev, const bioalign_b
     P.n = (uint32_t)n;
     P.m = (uint32_t)x.m;
     P.strips = (uint32_t)x.strips;
+    P.nsuper = (uint32_t)x.nsuper;
+    P.bnd_stride = (uint32_t)((x.m + 63) / 64 * 64);
     P.words_per_strip = (uint32_t)x.wps;
     P.rowprof = x.prof.as<uint32_t>();
     P.code1 = x.c1.as<uint8_t>();
@@ -1421,6 +1429,7 @@ int stripe_init(bioalign_stripe &x, bioalign_ctx *ctx, int dev, const bioalign_b
     P.start_i = 0;
     P.start_j = -1;
     P.scan_only = 0;
+    P.dbg = (int)env_u64("BIOALIGN_LONG_DBG", 0);
     return 0;
 }
 

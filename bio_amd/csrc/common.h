@@ -104,13 +104,15 @@ struct BaLongParams {
     const uint8_t *s1, *s2;        // the pair's raw bytes (device)
     uint32_t n, m;
     uint32_t strips;               // ceil(n / (64*T)), bottom aligned
+    uint32_t nsuper;               // workgroups = ceil(strips / strips per workgroup); the last strip is the last wave of the last one
     uint32_t words_per_strip;      // residue dwords per lane per strip = ceil((m + 63) / CPD)
     const uint32_t *rowprof;       // [na + 1] dwords: bytes w(a, b) + 2g for b = 0..3; entry na = padding (-128)
     const uint8_t *code1, *code2;  // [256] byte -> dense code
     int pad_code;                  // = na
     int gap;
-    int32_t *bnd;                  // [strips][m] bottom row of every strip, working-space scores
-    uint32_t *flags;               // [strips] 64-column blocks of bnd handed over so far
+    int32_t *bnd;                  // [nsuper][bnd_stride] bottom row of every workgroup's last strip, working-space scores
+    uint32_t bnd_stride;           // m rounded up to 64: every 64-column block of a row is two whole 128-byte lines
+    uint32_t *flags;               // [nsuper] 64-column blocks of bnd handed over so far
     uint32_t *resid;               // [strips][words_per_strip][64 lanes]
     uint32_t *status;              // != 0: a wait ran out (should never happen)
     // traceback
@@ -131,6 +133,7 @@ struct BaLongParams {
     int32_t *right_col;            // [n + 1] out: Hs(i, col0 + m) (null: not wanted)
     int start_i, start_j;          // walk: start from this cell instead of looking for the end cell (start_j < 0: look for it)
     int scan_only;                 // walk: find the end cell of this stripe's bottom row, report it, stop
+    int dbg;                       // experiments (BIOALIGN_LONG_DBG)
 };
 
 // FASTA text -> concatenated sequences + offsets (kernels_fasta.hip)

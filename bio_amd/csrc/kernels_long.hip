@@ -23,21 +23,24 @@
 //     store instruction; the traceback undoes the skew (step = column + lane).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "device_helpers.h"
 
-#define BA_LONG_FINAL 0x7fffffffu
+// the cell's substitution score: 0 = v_bfe_i32 + v_add, 1 = one v_dot4c_i32_i8 with the one-hot column symbol
+#ifndef BA_LONG_CELL
+#define BA_LONG_CELL 0
+#endif
+#define BA_LONG_FINAL 0x7fffffffu   // progress word: every column has been handed over
+#define BA_LONG_POISON 0x80000000u  // progress word, top bit: a wait ran out upstream; do not wait for this strip
+#define BA_LONG_W 4                 // strips (wavefronts) per workgroup: one per SIMD of a CU
+#define BA_LONG_RB 32                // depth, in 64-column blocks, of the ring a strip hands its bottom row over in
 
 // lane l <- lane l-1; lane 0 keeps `first`
 __device__ __forceinline__ int ba_wave_shr1(int first, int src)
 {
     return __builtin_amdgcn_update_dpp(first, src, 0x138, 0xf, 0xf, false);
-}
-// lane l <- lane l+1; lane 63 keeps `last`
-__device__ __forceinline__ int ba_wave_shl1(int last, int src)
-{
-    return __builtin_amdgcn_update_dpp(last, src, 0x130, 0xf, 0xf, false);
 }
 
 // Waits until every store this wave has issued has been acknowledged, and keeps the compiler
@@ -49,6 +52,18 @@ __device__ __forceinline__ void ba_stores_done()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 }
 
+// One dword to LDS, never merged with a neighbour into a ds_write2_b32.  Seen on gfx950 (MI355X, ROCm 7.2): after
+//   ds_write2_b32 vA, vD0, vD1 ...   /   v_alignbit_b32 vD1, ...
+// back to back, LDS received the NEW vD1 -- the store hands its three source dwords over at two cycles each
+// (MI355X_MICROARCH.md, LDS) and nothing holds the next VALU write back; hipcc pads only stores of more than 64 bits
+// of data.  The merged form appeared (54 times) once the steps were unrolled; an atomic store stays a ds_write_b32,
+// whose one data dword is gone before a following instruction can write it.  tools/scan_ds_write2.py looks for the
+// pattern in a hipcc -S dump.
+__device__ __forceinline__ void ba_lds_store(int32_t *p, int v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int T, int K>
 struct BaLongGeom {
     static constexpr int RS = 64 * T;          // rows per strip
@@ -56,18 +71,30 @@ struct BaLongGeom {
     static_assert(CPD >= 1 && CPD * T * K == 32, "T * K must divide 32");
 };
 
-// One step of one lane: T cells of one column.  ACTIVE_CHECK: the lane may be outside
-// its column range (start-up and drain of the skew) and must then keep its state.
+// What one strip (wavefront) keeps in LDS, dwords.  Windows hold two 64-column blocks, [previous | current]:
+// lane l at step k of a block works on window slot 64 + k - l.
+struct BaLongWaveLds {
+    uint32_t ohw[128];                // column symbols in the form the cell wants them (see ba_long_step)
+    int32_t bww[128];                 // this strip's bottom row being collected (the last writer of a slot is lane 63)
+};
+
+// One step of one lane: T cells of one column.
+// CHECK: the lane may be outside its column range (start-up and drain of the skew) and must then keep its state.
 template <int T, int K, bool CHECK>
 __device__ __forceinline__ void ba_long_step(int (&h)[T], const uint32_t (&prow)[T], uint32_t &acc, int top, int diag0,
-                                             uint32_t bshift, bool active)
+                                             uint32_t oh, bool active)
 {
     int up = top, diag = diag0;
 #pragma unroll
     for (int r = 0; r < T; ++r) {
         const int left = h[r];
-        const int w = __builtin_amdgcn_sbfe((int)prow[r], bshift, 8);
-        int hn = ba_max3(up, left, diag + w);
+#if BA_LONG_CELL == 1
+        // the score is the dot product of the row's four score bytes with the column symbol's one-hot bytes
+        const int d = __builtin_amdgcn_sdot4((int)prow[r], (int)oh, diag, false);
+#else
+        const int d = diag + __builtin_amdgcn_sbfe((int)prow[r], oh, 8);  // oh = 8 * the column symbol's code
+#endif
+        int hn = ba_max3(up, left, d);
         if (CHECK) hn = active ? hn : left;
         acc = __builtin_amdgcn_alignbit((uint32_t)hn, acc, K);
         diag = left;
@@ -76,27 +103,163 @@ __device__ __forceinline__ void ba_long_step(int (&h)[T], const uint32_t (&prow)
     }
 }
 
+// The DP of one pair.  A workgroup is BA_LONG_W consecutive strips, one wavefront each (one per SIMD of a CU), plus two
+// helper wavefronts that do nothing but move boundary rows; compute wave w of workgroup S runs strip s = S*W + w - pad
+// (pad: phantom waves above the matrix in the first workgroup, so that the last strip is the last wave of the last
+// workgroup).  Every hand-over inside the workgroup goes through a ring of 64-column blocks in LDS behind two counters
+// in LDS (sub-blocks of 16 columns published by the producer, sub-blocks consumed by the reader): ring r is written by
+// compute wave r-1 and read by compute wave r, so a strip lags the one above by 63 + 16 steps plus the hand-over.
+//   ring 0 (ring `pad` in the first workgroup) is filled by the IN helper: the top border's closed form for strip 0,
+//     otherwise the bottom row of the workgroup above, from HBM/L2: poll of its progress word, then sc1 loads
+//     (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads"), several blocks in flight;
+//   ring W is drained by the OUT helper: sc1 stores of whole 256-byte blocks, s_waitcnt vmcnt(0), then the progress
+//     word (the helper has no other memory traffic, so the wait is exact and costs the compute waves nothing).
+// Every wait is bounded; a wait that runs out raises a flag in LDS that ends every other wait of the workgroup,
+// poisons the progress words downstream, and the host reports the run as failed.  (The cross-workgroup wait assumes
+// what the status word guards: a workgroup's predecessor is resident or finished, which holds while workgroups are
+// dispatched in index order.)
 template <int MODE, int T, int K>
-__global__ void __launch_bounds__(64) ba_long_dp_kernel(BaLongParams P)
+__global__ void __launch_bounds__(64 * (BA_LONG_W + 2)) ba_long_dp_kernel(BaLongParams P)
 {
     using G = BaLongGeom<T, K>;
-    constexpr int RS = G::RS, CPD = G::CPD;
+    constexpr int RS = G::RS, CPD = G::CPD, W = BA_LONG_W, RB = BA_LONG_RB;
     __shared__ uint32_t code2s[64];  // byte -> code of the column side, packed
-    const int lane = threadIdx.x;
-    const int s = blockIdx.x;
+    __shared__ BaLongWaveLds wl[W];
+    __shared__ int32_t rings[W + 1][RB * 64];
+    __shared__ uint32_t prog_s[W + 1];   // sub-blocks of 16 columns put into ring r so far
+    __shared__ uint32_t cons_s[W + 1];   // sub-blocks of ring r its reader is done with
+    __shared__ uint32_t fail_s;          // a wait has run out somewhere in this workgroup
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = blockIdx.x;
     const int n = (int)P.n, m = (int)P.m, g = P.gap;
     const int strips = (int)P.strips;
-    code2s[lane] = reinterpret_cast<const uint32_t *>(P.code2)[lane];
+    const int pad = (int)P.nsuper * W - strips;
+    if (threadIdx.x < 64) code2s[threadIdx.x] = reinterpret_cast<const uint32_t *>(P.code2)[threadIdx.x];
+    if (threadIdx.x <= W) {
+        prog_s[threadIdx.x] = 0;
+        cons_s[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) fail_s = 0;
+    __syncthreads();  // (the only barrier: waves leave at different times below)
+
+    const int total_steps = m + 63;
+    const int nblk = (total_steps + 63) / 64;
+    const int first_ring = (S == 0) ? pad : 0;  // the ring the IN helper fills: the first real strip of the workgroup reads it
+    const int b_top = (MODE == BA_FITTING) ? g : 0;   // Hs(0, j) = b_top * j
+    const int b_left = (MODE == BA_OVERLAP) ? g : 0;  // Hs(i, 0) = b_left * i
+    const int col0 = (int)P.col0;  // column stripes: my column 0 is column col0 of the matrix
+
+    auto ld = [](uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto st = [](uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    // a bounded wait on a counter in LDS: until *word >= need (or the workgroup has failed)
+    auto wait_lds = [&](uint32_t *word, uint32_t need) {
+        if (ld(word) >= need) return;
+        int spin = 0;
+        for (; spin < (1 << 22); ++spin) {
+            if (ld(word) >= need || ld(&fail_s)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (spin == (1 << 22)) st(&fail_s, 1u);
+    };
+    // after the writes of a ring block: they are in LDS before the counter says so
+    auto publish = [&](uint32_t *word, uint32_t v) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) st(word, v);
+    };
+
+    // ---------------- IN helper: the row above the workgroup's first strip -> ring first_ring ----------------
+    if (w == W) {
+        const int32_t *bnd_in = P.bnd + (size_t)(S > 0 ? S - 1 : 0) * P.bnd_stride;
+        const uint32_t *flag_in = P.flags + (S > 0 ? S - 1 : 0);
+        int32_t *ring = rings[first_ring];
+        const int nb_in = (m + 63) / 64;  // blocks that hold columns of the matrix
+        uint32_t seen = 0;
+        for (int b = 0; b < nb_in;) {
+            int cnt = 1;
+            if (S > 0) {
+                if (seen < (uint32_t)b + 1) {
+                    int spin = 0;
+                    for (; spin < (1 << 22); ++spin) {
+                        seen = __hip_atomic_load(flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (seen >= (uint32_t)b + 1 || ld(&fail_s)) break;  // (a poisoned word has its top bit set: above everything)
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    if (spin == (1 << 22) || (seen & BA_LONG_POISON)) st(&fail_s, 1u);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                // everything the word allows, up to four blocks, in flight together
+                cnt = (int)min((uint32_t)min(nb_in - b, 4), (seen & ~BA_LONG_POISON) - (uint32_t)b);
+                if (cnt < 1) cnt = 1;
+            }
+            // the ring slots of these blocks held blocks b - RB ..: their reader must be done with them
+            if (b + cnt > RB) wait_lds(&cons_s[first_ring], 4u * (uint32_t)(b + cnt - RB));
+            int v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = (b + q) * 64 + lane;
+                if (S == 0)
+                    v[q] = b_top * (col0 + col + 1);
+                else
+                    v[q] = (q < cnt && col < m) ? __hip_atomic_load(bnd_in + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < cnt) ring[((b + q) & (RB - 1)) * 64 + lane] = v[q];
+            b += cnt;
+            publish(&prog_s[first_ring], 4u * (uint32_t)b);
+        }
+        return;
+    }
+    // ---------------- OUT helper: ring W -> the bottom row of the workgroup's last strip, in HBM ----------------
+    if (w == W + 1) {
+        int32_t *bnd_out = P.bnd + (size_t)S * P.bnd_stride;
+        uint32_t *flag_out = P.flags + S;
+        const int32_t *ring = rings[W];
+        const int nb_out = (m + 63) / 64;
+        for (int b = 0; b < nb_out;) {
+            // block b is whole once the producer has published its four sub-blocks (at its end: everything)
+            wait_lds(&prog_s[W], 4u * (uint32_t)b + 4u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t have = ld(&prog_s[W]) / 4u;
+            int cnt = (int)min((uint32_t)min(nb_out - b, 4), have > (uint32_t)b ? have - (uint32_t)b : 1u);
+            if (ld(&fail_s)) cnt = min(nb_out - b, 4);  // (a failed run: just get to the end)
+            int v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = q < cnt ? ring[((b + q) & (RB - 1)) * 64 + lane] : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = (b + q) * 64 + lane;
+                if (q < cnt && col < m) __hip_atomic_store(bnd_out + col, v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            b += cnt;
+            publish(&cons_s[W], 4u * (uint32_t)b);  // (the values are in registers: the ring slots are free again)
+            ba_stores_done();  // every store acknowledged before the word says so
+            if (lane == 0 && b < nb_out) __hip_atomic_store(flag_out, (uint32_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            const bool failed = ld(&fail_s) != 0;
+            __hip_atomic_store(flag_out, failed ? (BA_LONG_POISON | BA_LONG_FINAL) : BA_LONG_FINAL, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            if (failed) atomicAdd(P.status, 1u);
+        }
+        return;
+    }
+
+    // ---------------- compute waves ----------------
+    const int s = S * W + w - pad;
+    if (s < 0) return;  // phantom strip above the matrix
     const uint8_t *code2 = reinterpret_cast<const uint8_t *>(code2s);
+    BaLongWaveLds &L = wl[w];
+    const int32_t *ring_in = rings[w];
+    int32_t *ring_out = rings[w + 1];
+    uint32_t *prog_in = &prog_s[w], *cons_in = &cons_s[w], *prog_out = &prog_s[w + 1], *cons_out = &cons_s[w + 1];
 
     // bottom-aligned strips: strip s covers rows i0+1 .. i0+RS; rows <= 0 (first strip only)
     // carry the padding code and reproduce row 0 (see kernels.hip)
     const int i0 = n - (strips - s) * RS;
-    const int b_top = (MODE == BA_FITTING) ? g : 0;   // Hs(0, j) = b_top * j
-    const int b_left = (MODE == BA_OVERLAP) ? g : 0;  // Hs(i, 0) = b_left * i
-    // column stripes: my column 0 is column col0 of the matrix, handed over by the stripe to the left
-    const int col0 = (int)P.col0;
-    const int32_t *left_col = P.left_col;
+    const int32_t *left_col = P.left_col;  // column stripes: handed over by the stripe to the left
     auto first_col = [&](int i) { return left_col ? left_col[max(i, 0)] : b_left * max(i, 0); };
     int h[T];
     uint32_t prow[T];
@@ -107,10 +270,6 @@ __global__ void __launch_bounds__(64) ba_long_dp_kernel(BaLongParams P)
         prow[r] = P.rowprof[code];
         h[r] = first_col(i);
     }
-    int32_t *bnd_out = P.bnd + (size_t)s * m;
-    const int32_t *bnd_in = P.bnd + (size_t)(s > 0 ? s - 1 : 0) * m;
-    uint32_t *flag_out = P.flags + s;
-    const uint32_t *flag_in = P.flags + (s > 0 ? s - 1 : 0);
     uint32_t *resid = P.resid + (size_t)s * P.words_per_strip * 64 + lane;
 
     // skew state: `bottom` = my last row after the previous step; the lane below me reads it
@@ -118,80 +277,101 @@ __global__ void __launch_bounds__(64) ba_long_dp_kernel(BaLongParams P)
     // score above my first row in the column BEFORE my current one (the diagonal of my first row);
     // before the first step that is column 0 of the row above: my upper neighbour's initial bottom
     int topprev = ba_wave_shr1(first_col(i0), bottom);
-    int bsym = 0;    // my current column's symbol code * 8
-    int sreg = 0;    // column symbols of the current block of 64 steps, lane 0 reads its own
-    int bin = 0;     // boundary row of the strip above for the same block
-    int bout = 0;    // my strip's bottom row being collected for a 64-column store
     uint32_t acc = 0;
-    const int total_steps = m + 63;
-    uint32_t seen = 0;
-    bool failed = false;
 
-    __syncthreads();
-    for (int t0 = 0; t0 < total_steps; t0 += 64) {
-        // inputs of this block of 64 steps: column (0-based) t0 + lane for lane 0's steps t0 .. t0+63
-        {
-            const int col = t0 + lane;
-            sreg = col < m ? 8 * (int)code2[P.s2[col]] : 0;
-            if (s > 0 && t0 < m) {
-                const uint32_t need = (uint32_t)(t0 / 64 + 1);
-                if (seen < need) {
-                    int spin = 0;
-                    for (; spin < (1 << 22); ++spin) {
-                        seen = __hip_atomic_load(flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (seen >= need) break;
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                    if (spin == (1 << 22)) {  // give up waiting for good; the host reports the run as failed
-                        failed = true;
-                        seen = BA_LONG_FINAL;
+    // my window slots for step 0 of a block
+    const uint32_t *oh_me = L.ohw + 64 - lane;
+    int32_t *bw_me = L.bww + 64 - lane;
+
+    auto load_symbols = [&](int b) -> uint32_t {  // the column symbol of column b*64 + lane (0-based), as the cell wants it
+        const int col = b * 64 + lane;
+#if BA_LONG_CELL == 1
+        return col < m ? (1u << (8 * (uint32_t)code2[P.s2[col]])) : 0u;
+#else
+        return col < m ? 8u * (uint32_t)code2[P.s2[col]] : 0u;
+#endif
+    };
+    uint32_t ohnext = load_symbols(0);
+
+    for (int b = 0; b < nblk; ++b) {
+        const int t0 = b * 64;
+        // ---- inputs of this block ----
+        L.ohw[64 + lane] = ohnext;
+        if (b + 1 < nblk) ohnext = load_symbols(b + 1);
+        const int32_t *tin_base = ring_in + (b & (RB - 1)) * 64;
+        uint32_t *resid_blk = resid + (size_t)(t0 / CPD) * 64;
+        // all lanes inside their column range for the whole block?
+        const bool steady = (b >= 1) && (t0 + 64 <= m) && !(P.dbg & 1);
+        // the ring slot this block's hand-overs go to held block b-1-RB: its reader must be done with it
+        if (b >= 1 + RB) wait_lds(cons_out, 4u * (uint32_t)(b - RB));
+
+        uint32_t oh[16];
+        int tin[16];
+        for (int j = 0; j < 4; ++j) {
+            // columns j*16 .. j*16+15 of the row above must have been handed over (columns >= m never are: nobody reads them)
+            if (t0 + j * 16 < m) {
+                wait_lds(prog_in, 4u * (uint32_t)b + (uint32_t)j + 1u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                oh[k] = oh_me[j * 16 + k];
+                tin[k] = tin_base[j * 16 + k];
+            }
+            const int tj = t0 + j * 16;
+            if (steady) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int top = ba_wave_shr1(tin[k], bottom);
+                    ba_long_step<T, K, false>(h, prow, acc, top, topprev, oh[k], true);
+                    topprev = top;
+                    bottom = h[T - 1];
+                    ba_lds_store(bw_me + j * 16 + k, bottom);
+                    if ((k + 1) % CPD == 0) resid_blk[(size_t)((j * 16 + k) / CPD) * 64] = acc;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int t = tj + k;
+                    if (t < total_steps) {
+                        const int top = ba_wave_shr1(tin[k], bottom);
+                        const bool active = (t >= lane) && (t - lane < m);
+                        ba_long_step<T, K, true>(h, prow, acc, top, topprev, oh[k], active);
+                        topprev = top;
+                        bottom = h[T - 1];
+                        ba_lds_store(bw_me + j * 16 + k, bottom);
+                        if ((k + 1) % CPD == 0) resid_blk[(size_t)((j * 16 + k) / CPD) * 64] = acc;
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                bin = col < m ? __hip_atomic_load(bnd_in + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            }
+            publish(cons_in, 4u * (uint32_t)b + (uint32_t)j + 1u);  // (the values read are in registers or used up)
+            // hand-over: after these 16 steps the columns of sub-block j of block b-1 are final (column c is final
+            // once lane 63 has passed it, after step c + 63); the slots further right still change and are copied
+            // again later
+            if (b >= 1) {
+                const int v = L.bww[lane];
+                ring_out[((b - 1) & (RB - 1)) * 64 + lane] = v;
+                publish(prog_out, 4u * (uint32_t)(b - 1) + (uint32_t)j + 1u);
             }
         }
-        const int t_end = min(t0 + 64, total_steps);
-        // all lanes inside their column range for the whole block?
-        const bool steady = (t0 >= 63) && (t_end <= m);
-        for (int t = t0; t < t_end; ++t) {
-            // the row above my first row, in my current column: lane 0 takes the boundary
-            const int top_in = (s == 0) ? b_top * (col0 + t + 1) : bin;
-            const int top = ba_wave_shr1(top_in, bottom);
-            bsym = ba_wave_shr1(sreg, bsym);
-            if (steady) {
-                ba_long_step<T, K, false>(h, prow, acc, top, topprev, (uint32_t)bsym, true);
-            } else {
-                const bool active = (t >= lane) && (t - lane < m);
-                ba_long_step<T, K, true>(h, prow, acc, top, topprev, (uint32_t)bsym, active);
-            }
-            topprev = top;
-            bottom = h[T - 1];
-            bout = ba_wave_shl1(bottom, bout);
-            sreg = ba_wave_shl1(sreg, sreg);
-            bin = ba_wave_shl1(bin, bin);
-            if ((t + 1) % CPD == 0) resid[(size_t)(t / CPD) * 64] = acc;
-            if ((t & 63) == 62 && t >= 126) {
-                // lanes hold the bottom row of columns (0-based) t-125 .. t-62: one 256-byte line
-                const int q = (t - 126) / 64;
-                __hip_atomic_store(bnd_out + q * 64 + lane, bout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ba_stores_done();  // the line is out before the word says so
-                if (lane == 0) __hip_atomic_store(flag_out, (uint32_t)(q + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        // ---- end of the block: the windows move on ----
+        {
+            const uint32_t o = L.ohw[64 + lane];
+            const int v = L.bww[64 + lane];
+            L.ohw[lane] = o;
+            L.bww[lane] = v;
         }
     }
     // last, partial residue word: its pushes sit at the top, bring them down to their places
     if (total_steps % CPD != 0)
         resid[(size_t)(total_steps / CPD) * 64] = acc >> ((CPD - total_steps % CPD) * T * K);
-    // the columns not yet handed over: after the last step (t = m + 62) lane l holds column (0-based) m - 64 + l
+    // the columns not yet handed over: block nblk-1, now the left half of the window, all final
     {
-        const int col = m - 64 + lane;
-        const int done = (m / 64) * 64;  // full blocks stored above cover columns < done
-        if (col >= done && col >= 0) __hip_atomic_store(bnd_out + col, bout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ba_stores_done();
-        if (lane == 0) __hip_atomic_store(flag_out, BA_LONG_FINAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nblk - 1 >= RB) wait_lds(cons_out, 4u * (uint32_t)(nblk - RB));
+        const int v = L.bww[lane];
+        ring_out[((nblk - 1) & (RB - 1)) * 64 + lane] = v;
+        publish(prog_out, 4u * (uint32_t)nblk);
     }
-    if (failed && lane == 0) atomicAdd(P.status, 1u);
     // column stripes: my last column is the next stripe's column 0
     if (P.right_col) {
 #pragma unroll
@@ -243,7 +423,7 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
     const int b_left = (MODE == BA_OVERLAP) ? g : 0;
     constexpr bool top_free = (MODE == BA_FITTING);
     constexpr bool left_free = (MODE == BA_OVERLAP);
-    const int32_t *bottom_row = P.bnd + (size_t)(strips - 1) * m;
+    const int32_t *bottom_row = P.bnd + (size_t)(P.nsuper - 1) * P.bnd_stride;  // the last strip is the last wave of the last workgroup
     // column stripes: columns are the stripe's own (1..m), column 0 belongs to the stripe on the left
     const int col0 = (int)P.col0;
     const int32_t *left_col = P.left_col;
@@ -518,15 +698,15 @@ __global__ void __launch_bounds__(1024) ba_long_expand_kernel(BaLongParams P)
 template <int MODE, int T, int K>
 static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
 {
-    // 84 KB of (unused) dynamic LDS: at most one strip per CU, the placement the sc1 hand-off was measured in
-    // (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads"); strips beyond the CU count queue up behind
-    // the ones they depend on
+    // 84 KB of (unused) dynamic LDS: at most one workgroup per CU -- each of its four strips has a SIMD to itself,
+    // and it is the placement the sc1 hand-off was measured in (MI355X_MICROARCH.md, "Hand-offs measured with sc1
+    // loads"); workgroups beyond the CU count queue up behind the ones they depend on
     const size_t pad_lds = 84 * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
     hipError_t e = hipSuccess;
     if (phases & BA_LONG_PHASE_DP) {
-        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K>), dim3(P.strips), dim3(64), pad_lds, st, P);
+        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K>), dim3(P.nsuper), dim3(64 * (BA_LONG_W + 2)), pad_lds, st, P);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (phases & BA_LONG_PHASE_WALK) {
@@ -541,19 +721,31 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
 template <int MODE>
 static hipError_t launch_long_mode(const BaLongParams &P, int T, int K, int phases, hipStream_t st)
 {
-    if (T == 8 && K == 2) return launch_long<MODE, 8, 2>(P, phases, st);
-    if (T == 8 && K == 4) return launch_long<MODE, 8, 4>(P, phases, st);
+    if (T == 2 && K == 2) return launch_long<MODE, 2, 2>(P, phases, st);
+    if (T == 2 && K == 4) return launch_long<MODE, 2, 4>(P, phases, st);
+    if (T == 2 && K == 8) return launch_long<MODE, 2, 8>(P, phases, st);
+    if (T == 4 && K == 2) return launch_long<MODE, 4, 2>(P, phases, st);
+    if (T == 4 && K == 4) return launch_long<MODE, 4, 4>(P, phases, st);
     if (T == 4 && K == 8) return launch_long<MODE, 4, 8>(P, phases, st);
     return hipErrorInvalidValue;
 }
 
-// rows per lane for a residue width: T * K divides 32
-extern "C" int ba_long_rows_per_lane(int K) { return K == 8 ? 4 : 8; }
+// rows per lane (T * K divides 32).  The critical path of one pair is about T * m + 2 * n cell latencies (a strip is
+// 64 * T rows, each strip starts about 2 * 64 steps after the one above), and its width is n / (64 * T) wavefronts:
+// short strips win until the wavefronts outnumber the SIMDs.  BIOALIGN_LONG_T=4 for experiments.
+extern "C" int ba_long_rows_per_lane(int K)
+{
+    (void)K;
+    const char *e = getenv("BIOALIGN_LONG_T");
+    return (e && atoi(e) == 4) ? 4 : 2;
+}
+// strips per workgroup
+extern "C" int ba_long_strips_per_group(void) { return BA_LONG_W; }
 
 // phases: BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK (the walk includes the expansion of its moves into bytes)
 extern "C" hipError_t ba_launch_long(const BaLongParams &P, int mode, int T, int K, int phases, hipStream_t st)
 {
-    if (P.n == 0 || P.m == 0 || P.strips == 0) return hipErrorInvalidValue;
+    if (P.n == 0 || P.m == 0 || P.strips == 0 || (uint64_t)P.nsuper * BA_LONG_W < P.strips) return hipErrorInvalidValue;
     switch (mode) {
     case BA_GLOBAL: return launch_long_mode<BA_GLOBAL>(P, T, K, phases, st);
     case BA_FITTING: return launch_long_mode<BA_FITTING>(P, T, K, phases, st);
