@@ -1195,11 +1195,11 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     const uint64_t wps = (m + 63 + cpd - 1) / cpd;
 
     HIP_TRY(ctx, hipSetDevice(ctx->devices[0]));
-    DevBuf d_s1, d_s2, d_prof, d_c1, d_c2, d_tab, d_bnd, d_flags, d_res, d_misc, d_t1, d_t2, d_ops;
+    DevBuf d_s1, d_s2, d_prof, d_c1, d_c2, d_tab, d_bnd, d_res, d_misc, d_t1, d_t2, d_ops;
     int rc;
     if ((rc = d_s1.alloc(ctx, n + 16)) || (rc = d_s2.alloc(ctx, m + 16)) || (rc = d_prof.alloc(ctx, rowprof.size() * 4)) ||
         (rc = d_c1.alloc(ctx, 256)) || (rc = d_c2.alloc(ctx, 256)) || (rc = d_tab.alloc(ctx, (size_t)in->na * in->nb * 4)) ||
-        (rc = d_bnd.alloc(ctx, nsuper * ((m + 63) / 64 * 64) * 4 + 256)) || (rc = d_flags.alloc(ctx, nsuper * 4 + 4)) ||
+        (rc = d_bnd.alloc(ctx, nsuper * ((m + 15) / 16 * 16) * 8 + 256)) ||
         (rc = d_res.alloc(ctx, strips * wps * 256)) || (rc = d_misc.alloc(ctx, 64)))
         return rc;
     const uint64_t cap = n + m;
@@ -1213,12 +1213,13 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     HIP_TRY(ctx, hipMemcpyAsync(d_c1.p, in->code1, 256, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d_c2.p, in->code2, 256, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d_tab.p, in->score_table, (size_t)in->na * in->nb * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemsetAsync(d_flags.p, 0, nsuper * 4 + 4, st));
+    HIP_TRY(ctx, hipMemsetAsync(d_bnd.p, 0, nsuper * ((m + 15) / 16 * 16) * 8 + 256, st));  // tag 0: not handed over yet
     HIP_TRY(ctx, hipMemsetAsync(d_misc.p, 0, 64, st));
 
     BaLongParams P;
     P.nsuper = (uint32_t)nsuper;
-    P.bnd_stride = (uint32_t)((m + 63) / 64 * 64);
+    P.bnd_stride = (uint32_t)((m + 15) / 16 * 16);
+    P.epoch = 1;
     P.s1 = d_s1.as<uint8_t>();
     P.s2 = d_s2.as<uint8_t>();
     P.n = (uint32_t)n;
@@ -1231,7 +1232,6 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     P.pad_code = in->na;
     P.gap = g;
     P.bnd = d_bnd.as<int32_t>();
-    P.flags = d_flags.as<uint32_t>();
     P.resid = d_res.as<uint32_t>();
     // misc: [0] status, [8] score, [16] t_off, [24] t_len, [32..43] walk
     P.status = d_misc.as<uint32_t>();
@@ -1252,7 +1252,6 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     P.start_i = 0;
     P.start_j = -1;
     P.scan_only = 0;
-    P.dbg = (int)env_u64("BIOALIGN_LONG_DBG", 0);
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(ctx, hipEventCreate(&e0));
@@ -1302,7 +1301,7 @@ struct bioalign_stripe {
     int mode = 0, T = 8, K = 2;
     uint64_t n = 0, c0 = 0, m = 0, m_total = 0, wps = 0, strips = 0, nsuper = 0;
     bool traces = true, dp_done = false;
-    DevBuf s1, s2, prof, c1, c2, bnd, flags, res, misc, t1, t2, ops, left, right;
+    DevBuf s1, s2, prof, c1, c2, bnd, res, misc, t1, t2, ops, left, right;
     hipStream_t st = nullptr;
     hipEvent_t done = nullptr;
     BaLongParams P;
@@ -1379,8 +1378,8 @@ int stripe_init(bioalign_stripe &x, bioalign_ctx *ctx, int dev, const bioalign_b
     HIP_TRY(ctx, hipEventCreateWithFlags(&x.done, hipEventDisableTiming));
     const uint64_t cap = n + x.m;
     if ((rc = x.s1.alloc(ctx, n + 16)) || (rc = x.s2.alloc(ctx, x.m + 16)) || (rc = x.prof.alloc(ctx, rowprof.size() * 4)) ||
-        (rc = x.c1.alloc(ctx, 256)) || (rc = x.c2.alloc(ctx, 256)) || (rc = x.bnd.alloc(ctx, x.nsuper * ((x.m + 63) / 64 * 64) * 4 + 256)) ||
-        (rc = x.flags.alloc(ctx, x.nsuper * 4 + 4)) || (rc = x.res.alloc(ctx, x.strips * x.wps * 256)) ||
+        (rc = x.c1.alloc(ctx, 256)) || (rc = x.c2.alloc(ctx, 256)) || (rc = x.bnd.alloc(ctx, x.nsuper * ((x.m + 15) / 16 * 16) * 8 + 256)) ||
+        (rc = x.res.alloc(ctx, x.strips * x.wps * 256)) ||
         (rc = x.misc.alloc(ctx, 64)) || (rc = x.left.alloc(ctx, (n + 1) * 4)) || (rc = x.right.alloc(ctx, (n + 1) * 4)))
         return rc;
     if (x.traces && ((rc = x.t1.alloc(ctx, cap + 32)) || (rc = x.t2.alloc(ctx, cap + 32)) ||
@@ -1391,7 +1390,7 @@ int stripe_init(bioalign_stripe &x, bioalign_ctx *ctx, int dev, const bioalign_b
     HIP_TRY(ctx, hipMemcpyAsync(x.prof.p, rowprof.data(), rowprof.size() * 4, hipMemcpyHostToDevice, x.st));
     HIP_TRY(ctx, hipMemcpyAsync(x.c1.p, in->code1, 256, hipMemcpyHostToDevice, x.st));
     HIP_TRY(ctx, hipMemcpyAsync(x.c2.p, in->code2, 256, hipMemcpyHostToDevice, x.st));
-    HIP_TRY(ctx, hipMemsetAsync(x.flags.p, 0, x.nsuper * 4 + 4, x.st));
+    HIP_TRY(ctx, hipMemsetAsync(x.bnd.p, 0, x.nsuper * ((x.m + 15) / 16 * 16) * 8 + 256, x.st));  // tag 0: not handed over yet
     HIP_TRY(ctx, hipMemsetAsync(x.misc.p, 0, 64, x.st));
     HIP_TRY(ctx, hipStreamSynchronize(x.st));  // rowprof is a local
     BaLongParams &P = x.P;
@@ -1401,7 +1400,8 @@ int stripe_init(bioalign_stripe &x, bioalign_ctx *ctx, int dev, const bioalign_b
     P.m = (uint32_t)x.m;
     P.strips = (uint32_t)x.strips;
     P.nsuper = (uint32_t)x.nsuper;
-    P.bnd_stride = (uint32_t)((x.m + 63) / 64 * 64);
+    P.bnd_stride = (uint32_t)((x.m + 15) / 16 * 16);
+    P.epoch = 1;
     P.words_per_strip = (uint32_t)x.wps;
     P.rowprof = x.prof.as<uint32_t>();
     P.code1 = x.c1.as<uint8_t>();
@@ -1409,7 +1409,6 @@ int stripe_init(bioalign_stripe &x, bioalign_ctx *ctx, int dev, const bioalign_b
     P.pad_code = in->na;
     P.gap = in->gap_open;
     P.bnd = x.bnd.as<int32_t>();
-    P.flags = x.flags.as<uint32_t>();
     P.resid = x.res.as<uint32_t>();
     P.status = x.misc.as<uint32_t>();
     P.table = nullptr;
@@ -1429,7 +1428,6 @@ int stripe_init(bioalign_stripe &x, bioalign_ctx *ctx, int dev, const bioalign_b
     P.start_i = 0;
     P.start_j = -1;
     P.scan_only = 0;
-    P.dbg = (int)env_u64("BIOALIGN_LONG_DBG", 0);
     return 0;
 }
 

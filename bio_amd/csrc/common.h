@@ -110,9 +110,10 @@ struct BaLongParams {
     const uint8_t *code1, *code2;  // [256] byte -> dense code
     int pad_code;                  // = na
     int gap;
-    int32_t *bnd;                  // [nsuper][bnd_stride] bottom row of every workgroup's last strip, working-space scores
-    uint32_t bnd_stride;           // m rounded up to 64: every 64-column block of a row is two whole 128-byte lines
-    uint32_t *flags;               // [nsuper] 64-column blocks of bnd handed over so far
+    int32_t *bnd;                  // [nsuper][bnd_stride] granules {working-space score, tag}, 8 bytes each: the bottom row of every
+                                   // workgroup's last strip; zeroed before the launch (tag 0 = not there yet)
+    uint32_t bnd_stride;           // granules per row: m rounded up to 16 (a sub-block of 16 columns is one whole 128-byte line)
+    uint32_t epoch;                // tag of this launch's granules: 1 .. 0x7ffffffe (top bit: poisoned)
     uint32_t *resid;               // [strips][words_per_strip][64 lanes]
     uint32_t *status;              // != 0: a wait ran out (should never happen)
     // traceback
@@ -133,7 +134,6 @@ struct BaLongParams {
     int32_t *right_col;            // [n + 1] out: Hs(i, col0 + m) (null: not wanted)
     int start_i, start_j;          // walk: start from this cell instead of looking for the end cell (start_j < 0: look for it)
     int scan_only;                 // walk: find the end cell of this stripe's bottom row, report it, stop
-    int dbg;                       // experiments (BIOALIGN_LONG_DBG)
 };
 
 // FASTA text -> concatenated sequences + offsets (kernels_fasta.hip)

@@ -34,7 +34,9 @@
 #endif
 #define BA_LONG_FINAL 0x7fffffffu   // progress word: every column has been handed over
 #define BA_LONG_POISON 0x80000000u  // progress word, top bit: a wait ran out upstream; do not wait for this strip
+#ifndef BA_LONG_W
 #define BA_LONG_W 4                 // strips (wavefronts) per workgroup: one per SIMD of a CU
+#endif
 #define BA_LONG_RB 32                // depth, in 64-column blocks, of the ring a strip hands its bottom row over in
 
 // lane l <- lane l-1; lane 0 keeps `first`
@@ -71,12 +73,14 @@ struct BaLongGeom {
     static_assert(CPD >= 1 && CPD * T * K == 32, "T * K must divide 32");
 };
 
-// What one strip (wavefront) keeps in LDS, dwords.  Windows hold two 64-column blocks, [previous | current]:
-// lane l at step k of a block works on window slot 64 + k - l.
+// What one strip (wavefront) keeps in LDS for itself, dwords.
 struct BaLongWaveLds {
-    uint32_t ohw[128];                // column symbols in the form the cell wants them (see ba_long_step)
-    int32_t bww[128];                 // this strip's bottom row being collected (the last writer of a slot is lane 63)
+    uint32_t ohw[128];   // column symbols in the form the cell wants them (see ba_long_step), window of two 64-column
+                         // blocks [previous | current]: lane l at step k of a block reads slot 64 + k - l
+    int32_t dummy[128];  // where the lanes other than 63 put their (not yet final) bottom-row values
 };
+
+#define BA_LONG_RING (BA_LONG_RB * 64)  // columns a hand-over ring holds
 
 // One step of one lane: T cells of one column.
 // CHECK: the lane may be outside its column range (start-up and drain of the skew) and must then keep its state.
@@ -103,31 +107,39 @@ __device__ __forceinline__ void ba_long_step(int (&h)[T], const uint32_t (&prow)
     }
 }
 
-// The DP of one pair.  A workgroup is BA_LONG_W consecutive strips, one wavefront each (one per SIMD of a CU), plus two
-// helper wavefronts that do nothing but move boundary rows; compute wave w of workgroup S runs strip s = S*W + w - pad
-// (pad: phantom waves above the matrix in the first workgroup, so that the last strip is the last wave of the last
-// workgroup).  Every hand-over inside the workgroup goes through a ring of 64-column blocks in LDS behind two counters
-// in LDS (sub-blocks of 16 columns published by the producer, sub-blocks consumed by the reader): ring r is written by
-// compute wave r-1 and read by compute wave r, so a strip lags the one above by 63 + 16 steps plus the hand-over.
-//   ring 0 (ring `pad` in the first workgroup) is filled by the IN helper: the top border's closed form for strip 0,
-//     otherwise the bottom row of the workgroup above, from HBM/L2: poll of its progress word, then sc1 loads
-//     (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads"), several blocks in flight;
-//   ring W is drained by the OUT helper: sc1 stores of whole 256-byte blocks, s_waitcnt vmcnt(0), then the progress
-//     word (the helper has no other memory traffic, so the wait is exact and costs the compute waves nothing).
-// Every wait is bounded; a wait that runs out raises a flag in LDS that ends every other wait of the workgroup,
-// poisons the progress words downstream, and the host reports the run as failed.  (The cross-workgroup wait assumes
-// what the status word guards: a workgroup's predecessor is resident or finished, which holds while workgroups are
-// dispatched in index order.)
+// The DP of one pair.  A workgroup is BA_LONG_W consecutive strips, one wavefront each (one per SIMD of a CU), plus one
+// helper wavefront; compute wave w of workgroup S runs strip s = S*W + w - pad (pad: phantom waves above the matrix in
+// the first workgroup, so that the last strip is the last wave of the last workgroup).
+//
+// Hand-over inside the workgroup: ring r (LDS, BA_LONG_RING columns, slot = column mod size) holds the bottom row of
+// compute wave r-1 and is read by compute wave r.  A column of a strip's bottom row is final once lane 63 has passed
+// it, so lane 63 alone writes the ring, one column per step (the other lanes' stores go to a scratch row), and the
+// producer publishes a column count every 16 steps; the reader needs column t at its step t, so a strip runs
+// 63 + 16 steps behind the one above plus the time the counter takes.  Both counters (columns final, columns the
+// reader is done with) live in LDS.
+//
+// Hand-over between workgroups, through HBM/L2: the last compute wave stores its final columns 16 at a time as
+// 8-byte granules {score, tag} -- one 128-byte line per store, agent scope (sc1), fire and forget; the tag is the
+// launch's epoch and the buffer is zeroed before the launch.  The helper wave of the workgroup below polls the
+// granules themselves (sc1 loads, up to four blocks in flight), copies the valid prefix into ring 0 (ring `pad` in
+// the first workgroup) and publishes it: no progress word, no store drain, one memory round trip per poll
+// (MI355X_MICROARCH.md, hand-off price list: data-tagged granules).  For strip 0 the helper writes the top border's
+// closed form instead.
+//
+// Every wait is bounded; a wait that runs out raises a flag in LDS that ends every other wait of the workgroup, the
+// rest of the workgroup's bottom row goes out with a poisoned tag, which fails the workgroups below at once, and the
+// host reports the run as failed.  (The cross-workgroup wait assumes what the status word guards: a workgroup's
+// predecessor is resident or finished, which holds while workgroups are dispatched in index order.)
 template <int MODE, int T, int K>
-__global__ void __launch_bounds__(64 * (BA_LONG_W + 2)) ba_long_dp_kernel(BaLongParams P)
+__global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLongParams P)
 {
     using G = BaLongGeom<T, K>;
-    constexpr int RS = G::RS, CPD = G::CPD, W = BA_LONG_W, RB = BA_LONG_RB;
+    constexpr int RS = G::RS, CPD = G::CPD, W = BA_LONG_W, RING = BA_LONG_RING;
     __shared__ uint32_t code2s[64];  // byte -> code of the column side, packed
     __shared__ BaLongWaveLds wl[W];
-    __shared__ int32_t rings[W + 1][RB * 64];
-    __shared__ uint32_t prog_s[W + 1];   // sub-blocks of 16 columns put into ring r so far
-    __shared__ uint32_t cons_s[W + 1];   // sub-blocks of ring r its reader is done with
+    __shared__ int32_t rings[W + 1][RING];
+    __shared__ uint32_t prog_s[W + 1];   // columns of ring r that are final (all columns below this number)
+    __shared__ uint32_t cons_s[W + 1];   // columns of ring r its reader is done with
     __shared__ uint32_t fail_s;          // a wait has run out somewhere in this workgroup
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -145,105 +157,94 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 2)) ba_long_dp_kernel(BaLong
 
     const int total_steps = m + 63;
     const int nblk = (total_steps + 63) / 64;
-    const int first_ring = (S == 0) ? pad : 0;  // the ring the IN helper fills: the first real strip of the workgroup reads it
+    const int first_ring = (S == 0) ? pad : 0;  // the ring the helper fills: the first real strip of the workgroup reads it
     const int b_top = (MODE == BA_FITTING) ? g : 0;   // Hs(0, j) = b_top * j
     const int b_left = (MODE == BA_OVERLAP) ? g : 0;  // Hs(i, 0) = b_left * i
     const int col0 = (int)P.col0;  // column stripes: my column 0 is column col0 of the matrix
+    const uint32_t epoch = P.epoch;
 
     auto ld = [](uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto st = [](uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-    // a bounded wait on a counter in LDS: until *word >= need (or the workgroup has failed)
-    auto wait_lds = [&](uint32_t *word, uint32_t need) {
-        if (ld(word) >= need) return;
+    // a bounded wait on a counter in LDS: until *word >= need (or the workgroup has failed); returns what it saw
+    auto wait_lds = [&](uint32_t *word, uint32_t need) -> uint32_t {
+        uint32_t v = ld(word);
+        if (v >= need) return v;
         int spin = 0;
         for (; spin < (1 << 22); ++spin) {
-            if (ld(word) >= need || ld(&fail_s)) break;
+            v = ld(word);
+            if (v >= need || ld(&fail_s)) break;
             __builtin_amdgcn_s_sleep(1);
         }
         if (spin == (1 << 22)) st(&fail_s, 1u);
+        return v >= need ? v : need;  // (a failed run goes on without waiting)
     };
-    // after the writes of a ring block: they are in LDS before the counter says so
+    // a counter behind the LDS writes it announces: one wavefront's LDS operations are carried out in the order they
+    // are issued, so the reader that sees the counter sees the writes; the fence only pins the compiler's order
     auto publish = [&](uint32_t *word, uint32_t v) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" ::: "memory");
         if (lane == 0) st(word, v);
     };
+    unsigned long long *bnd_out = reinterpret_cast<unsigned long long *>(P.bnd) + (size_t)S * P.bnd_stride;
 
-    // ---------------- IN helper: the row above the workgroup's first strip -> ring first_ring ----------------
+    // ---------------- helper: the row above the workgroup's first strip -> ring first_ring ----------------
     if (w == W) {
-        const int32_t *bnd_in = P.bnd + (size_t)(S > 0 ? S - 1 : 0) * P.bnd_stride;
-        const uint32_t *flag_in = P.flags + (S > 0 ? S - 1 : 0);
+        const unsigned long long *bnd_in = reinterpret_cast<const unsigned long long *>(P.bnd) + (size_t)(S > 0 ? S - 1 : 0) * P.bnd_stride;
         int32_t *ring = rings[first_ring];
-        const int nb_in = (m + 63) / 64;  // blocks that hold columns of the matrix
-        uint32_t seen = 0;
-        for (int b = 0; b < nb_in;) {
-            int cnt = 1;
-            if (S > 0) {
-                if (seen < (uint32_t)b + 1) {
-                    int spin = 0;
-                    for (; spin < (1 << 22); ++spin) {
-                        seen = __hip_atomic_load(flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (seen >= (uint32_t)b + 1 || ld(&fail_s)) break;  // (a poisoned word has its top bit set: above everything)
-                        __builtin_amdgcn_s_sleep(4);
-                    }
-                    if (spin == (1 << 22) || (seen & BA_LONG_POISON)) st(&fail_s, 1u);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                }
-                // everything the word allows, up to four blocks, in flight together
-                cnt = (int)min((uint32_t)min(nb_in - b, 4), (seen & ~BA_LONG_POISON) - (uint32_t)b);
-                if (cnt < 1) cnt = 1;
-            }
-            // the ring slots of these blocks held blocks b - RB ..: their reader must be done with them
-            if (b + cnt > RB) wait_lds(&cons_s[first_ring], 4u * (uint32_t)(b + cnt - RB));
-            int v[4];
+        int done = 0;  // columns handed to the ring so far: a multiple of 16 until the end
+        int idle = 0;
+        while (done < m) {
+            // room in the ring: the reader must be done with the columns these slots held
+            const int b0 = done / 64;  // the block the next column lies in; up to four blocks from here per round
+            uint32_t cons = ld(&cons_s[first_ring]);
+            if ((uint32_t)(b0 * 64 + 64) > cons + RING) cons = wait_lds(&cons_s[first_ring], (uint32_t)(b0 * 64 + 64 - RING));
+            const int room_blocks = (int)((cons + RING) / 64) - b0;
+            const int cnt = min(min(4, room_blocks), (m + 63) / 64 - b0);
+            unsigned long long gv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int col = (b + q) * 64 + lane;
+                const int col = (b0 + q) * 64 + lane;
                 if (S == 0)
-                    v[q] = b_top * (col0 + col + 1);
+                    gv[q] = ((unsigned long long)epoch << 32) | (uint32_t)(b_top * (col0 + col + 1));
                 else
-                    v[q] = (q < cnt && col < m) ? __hip_atomic_load(bnd_in + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    gv[q] = (q < cnt && col < m) ? __hip_atomic_load(bnd_in + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                 : ((unsigned long long)epoch << 32);
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q < cnt) ring[((b + q) & (RB - 1)) * 64 + lane] = v[q];
-            b += cnt;
-            publish(&prog_s[first_ring], 4u * (uint32_t)b);
-        }
-        return;
-    }
-    // ---------------- OUT helper: ring W -> the bottom row of the workgroup's last strip, in HBM ----------------
-    if (w == W + 1) {
-        int32_t *bnd_out = P.bnd + (size_t)S * P.bnd_stride;
-        uint32_t *flag_out = P.flags + S;
-        const int32_t *ring = rings[W];
-        const int nb_out = (m + 63) / 64;
-        for (int b = 0; b < nb_out;) {
-            // block b is whole once the producer has published its four sub-blocks (at its end: everything)
-            wait_lds(&prog_s[W], 4u * (uint32_t)b + 4u);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const uint32_t have = ld(&prog_s[W]) / 4u;
-            int cnt = (int)min((uint32_t)min(nb_out - b, 4), have > (uint32_t)b ? have - (uint32_t)b : 1u);
-            if (ld(&fail_s)) cnt = min(nb_out - b, 4);  // (a failed run: just get to the end)
-            int v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = q < cnt ? ring[((b + q) & (RB - 1)) * 64 + lane] : 0;
+            // valid prefix, in columns from b0 * 64
+            int prefix = 0;
+            bool open = true, poisoned = false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int col = (b + q) * 64 + lane;
-                if (q < cnt && col < m) __hip_atomic_store(bnd_out + col, v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t tag = (uint32_t)(gv[q] >> 32);
+                poisoned = poisoned || (q < cnt && __any(tag == (epoch | BA_LONG_POISON)));
+                const unsigned long long ok = __ballot(tag == epoch);
+                if (q < cnt) ring[((b0 + q) * 64 + lane) & (RING - 1)] = (int32_t)(uint32_t)gv[q];
+                if (q < cnt && open) {
+                    const int lead = ok == ~0ull ? 64 : (int)__builtin_ctzll(~ok);
+                    prefix += lead;
+                    open = lead == 64;
+                }
             }
-            b += cnt;
-            publish(&cons_s[W], 4u * (uint32_t)b);  // (the values are in registers: the ring slots are free again)
-            ba_stores_done();  // every store acknowledged before the word says so
-            if (lane == 0 && b < nb_out) __hip_atomic_store(flag_out, (uint32_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (poisoned) {
+                st(&fail_s, 1u);
+                break;
+            }
+            int upto = min(b0 * 64 + prefix, m);
+            if (upto < m) upto &= ~15;  // whole sub-blocks of 16 columns
+            if (upto > done) {
+                done = upto;
+                publish(&prog_s[first_ring], (uint32_t)done);
+                idle = 0;
+            } else {
+                if (++idle > (1 << 22)) {
+                    st(&fail_s, 1u);
+                    break;
+                }
+                if (ld(&fail_s)) break;
+                // back off while nothing arrives: a workgroup far behind the front polls for milliseconds
+                for (int z = 0; z < min(idle, 4); ++z) __builtin_amdgcn_s_sleep(8);
+            }
         }
-        if (lane == 0) {
-            const bool failed = ld(&fail_s) != 0;
-            __hip_atomic_store(flag_out, failed ? (BA_LONG_POISON | BA_LONG_FINAL) : BA_LONG_FINAL, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            if (failed) atomicAdd(P.status, 1u);
-        }
+        if (ld(&fail_s)) publish(&prog_s[first_ring], 0x7fffffffu);  // nobody waits for this ring any more
         return;
     }
 
@@ -255,6 +256,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 2)) ba_long_dp_kernel(BaLong
     const int32_t *ring_in = rings[w];
     int32_t *ring_out = rings[w + 1];
     uint32_t *prog_in = &prog_s[w], *cons_in = &cons_s[w], *prog_out = &prog_s[w + 1], *cons_out = &cons_s[w + 1];
+    const bool last_wave = (w == W - 1);  // my bottom row goes to the workgroup below (and to the traceback)
 
     // bottom-aligned strips: strip s covers rows i0+1 .. i0+RS; rows <= 0 (first strip only)
     // carry the padding code and reproduce row 0 (see kernels.hip)
@@ -279,9 +281,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 2)) ba_long_dp_kernel(BaLong
     int topprev = ba_wave_shr1(first_col(i0), bottom);
     uint32_t acc = 0;
 
-    // my window slots for step 0 of a block
-    const uint32_t *oh_me = L.ohw + 64 - lane;
-    int32_t *bw_me = L.bww + 64 - lane;
+    const uint32_t *oh_me = L.ohw + 64 - lane;  // my window slot for step 0 of a block
 
     auto load_symbols = [&](int b) -> uint32_t {  // the column symbol of column b*64 + lane (0-based), as the cell wants it
         const int col = b * 64 + lane;
@@ -292,33 +292,46 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 2)) ba_long_dp_kernel(BaLong
 #endif
     };
     uint32_t ohnext = load_symbols(0);
+    uint32_t pseen = 0;  // columns of the row above known to be final
+    int sent = 0;        // last wave: columns of my bottom row sent to HBM so far (a multiple of 16 until the end)
+    // last wave: columns [sent, upto) of ring_out are final; send them on, 16 granules (one 128-byte line) per store
+    auto send = [&](int upto, uint32_t tag) {
+        for (; sent + 16 <= upto || (upto == m && sent < m); sent += 16) {
+            const int col = sent + (lane & 15);
+            if (lane < 16 && col < m) {
+                const uint32_t v = (uint32_t)ring_out[col & (RING - 1)];
+                __hip_atomic_store(bnd_out + col, ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
 
     for (int b = 0; b < nblk; ++b) {
         const int t0 = b * 64;
         // ---- inputs of this block ----
         L.ohw[64 + lane] = ohnext;
         if (b + 1 < nblk) ohnext = load_symbols(b + 1);
-        const int32_t *tin_base = ring_in + (b & (RB - 1)) * 64;
+        const int32_t *tin_base = ring_in + (t0 & (RING - 1));
         uint32_t *resid_blk = resid + (size_t)(t0 / CPD) * 64;
         // all lanes inside their column range for the whole block?
-        const bool steady = (b >= 1) && (t0 + 64 <= m) && !(P.dbg & 1);
-        // the ring slot this block's hand-overs go to held block b-1-RB: its reader must be done with it
-        if (b >= 1 + RB) wait_lds(cons_out, 4u * (uint32_t)(b - RB));
+        const bool steady = (b >= 1) && (t0 + 64 <= m);
+        // lane 63 writes column t0 + k - 63 at step k: slots of block b-1 for k < 63, the first slot of block b for k = 63
+        // (the other lanes write to the scratch row).  The slots held columns RING further left: their reader must be done.
+        if (!last_wave && t0 + 1 > RING) wait_lds(cons_out, (uint32_t)(t0 + 1 - RING));
+        int32_t *wp = (lane == 63) ? ring_out + ((t0 - 63) & (RING - 1)) : L.dummy + lane;
+        int32_t *wp63 = (lane == 63) ? ring_out + (t0 & (RING - 1)) : L.dummy + lane;
 
-        uint32_t oh[16];
-        int tin[16];
-        for (int j = 0; j < 4; ++j) {
-            // columns j*16 .. j*16+15 of the row above must have been handed over (columns >= m never are: nobody reads them)
-            if (t0 + j * 16 < m) {
-                wait_lds(prog_in, 4u * (uint32_t)b + (uint32_t)j + 1u);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
+        uint32_t ohA[16], ohB[16];
+        int tinA[16], tinB[16];
+        // columns j*16 .. j*16+15 of the row above must be final (columns >= m never are: nobody reads them)
+        auto need_cols = [&](int j) -> uint32_t { return (uint32_t)min(t0 + j * 16 + 16, m); };
+        auto fetch = [&](uint32_t (&oh)[16], int (&tin)[16], int j) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 oh[k] = oh_me[j * 16 + k];
                 tin[k] = tin_base[j * 16 + k];
             }
-            const int tj = t0 + j * 16;
+        };
+        auto compute = [&](const uint32_t (&oh)[16], const int (&tin)[16], int j) {
             if (steady) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
@@ -326,51 +339,77 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 2)) ba_long_dp_kernel(BaLong
                     ba_long_step<T, K, false>(h, prow, acc, top, topprev, oh[k], true);
                     topprev = top;
                     bottom = h[T - 1];
-                    ba_lds_store(bw_me + j * 16 + k, bottom);
+                    ba_lds_store((j * 16 + k == 63) ? wp63 : wp + j * 16 + k, bottom);
                     if ((k + 1) % CPD == 0) resid_blk[(size_t)((j * 16 + k) / CPD) * 64] = acc;
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    const int t = tj + k;
+                    const int t = t0 + j * 16 + k;
                     if (t < total_steps) {
                         const int top = ba_wave_shr1(tin[k], bottom);
                         const bool active = (t >= lane) && (t - lane < m);
                         ba_long_step<T, K, true>(h, prow, acc, top, topprev, oh[k], active);
                         topprev = top;
                         bottom = h[T - 1];
-                        ba_lds_store(bw_me + j * 16 + k, bottom);
+                        ba_lds_store((j * 16 + k == 63) ? wp63 : wp + j * 16 + k, bottom);
                         if ((k + 1) % CPD == 0) resid_blk[(size_t)((j * 16 + k) / CPD) * 64] = acc;
                     }
                 }
             }
-            publish(cons_in, 4u * (uint32_t)b + (uint32_t)j + 1u);  // (the values read are in registers or used up)
-            // hand-over: after these 16 steps the columns of sub-block j of block b-1 are final (column c is final
-            // once lane 63 has passed it, after step c + 63); the slots further right still change and are copied
-            // again later
-            if (b >= 1) {
-                const int v = L.bww[lane];
-                ring_out[((b - 1) & (RB - 1)) * 64 + lane] = v;
-                publish(prog_out, 4u * (uint32_t)(b - 1) + (uint32_t)j + 1u);
+            // after step t every column up to t - 63 of my bottom row is final
+            const int fin = min(max(t0 + j * 16 + 15 - 62, 0), m);
+            if (last_wave)
+                send(fin, epoch);
+            else
+                publish(prog_out, (uint32_t)fin);
+        };
+        // sub-block j with its inputs in (oh, tin); the inputs of sub-block j+1 are fetched into (ohn, tinn) before the
+        // steps when the row above is known to be far enough, after them (waiting) otherwise
+        auto stage = [&](const uint32_t (&oh)[16], const int (&tin)[16], uint32_t (&ohn)[16], int (&tinn)[16], int j, bool more) {
+            // (compiler barriers, not fences: what orders the ring reads behind the counter read is the LDS itself,
+            // which carries out one wavefront's operations in the order they were issued)
+            asm volatile("" ::: "memory");
+            const uint32_t fresh = ld(prog_in);  // (in flight during the steps)
+            const bool early = more && pseen >= need_cols(j + 1);
+            if (early) fetch(ohn, tinn, j + 1);
+            compute(oh, tin, j);
+            pseen = max(pseen, fresh);
+            if (more && !early) {
+                if (pseen < need_cols(j + 1)) pseen = max(pseen, wait_lds(prog_in, need_cols(j + 1)));
+                asm volatile("" ::: "memory");
+                fetch(ohn, tinn, j + 1);
             }
-        }
-        // ---- end of the block: the windows move on ----
+        };
+        if (pseen < need_cols(0)) pseen = max(pseen, wait_lds(prog_in, need_cols(0)));
+        asm volatile("" ::: "memory");
+        fetch(ohA, tinA, 0);
+        stage(ohA, tinA, ohB, tinB, 0, true);
+        stage(ohB, tinB, ohA, tinA, 1, true);
+        stage(ohA, tinA, ohB, tinB, 2, true);
+        stage(ohB, tinB, ohA, tinA, 3, false);
+        // ---- end of the block ----
+        publish(cons_in, (uint32_t)min(t0 + 64, m));  // (the values read are in registers or used up)
         {
             const uint32_t o = L.ohw[64 + lane];
-            const int v = L.bww[64 + lane];
             L.ohw[lane] = o;
-            L.bww[lane] = v;
         }
     }
     // last, partial residue word: its pushes sit at the top, bring them down to their places
     if (total_steps % CPD != 0)
         resid[(size_t)(total_steps / CPD) * 64] = acc >> ((CPD - total_steps % CPD) * T * K);
-    // the columns not yet handed over: block nblk-1, now the left half of the window, all final
-    {
-        if (nblk - 1 >= RB) wait_lds(cons_out, 4u * (uint32_t)(nblk - RB));
-        const int v = L.bww[lane];
-        ring_out[((nblk - 1) & (RB - 1)) * 64 + lane] = v;
-        publish(prog_out, 4u * (uint32_t)nblk);
+    // every column is final now
+    const bool failed = ld(&fail_s) != 0;
+    if (last_wave) {
+        send(m, failed ? (epoch | BA_LONG_POISON) : epoch);
+        if (failed) {  // nobody below may wait for what was sent with a good tag before the failure either
+            for (int col = lane; col < m; col += 64)
+                __hip_atomic_store(bnd_out + col, (unsigned long long)(epoch | BA_LONG_POISON) << 32, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) atomicAdd(P.status, 1u);
+        }
+    } else {
+        publish(prog_out, (uint32_t)m);
     }
     // column stripes: my last column is the next stripe's column 0
     if (P.right_col) {
@@ -423,7 +462,8 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
     const int b_left = (MODE == BA_OVERLAP) ? g : 0;
     constexpr bool top_free = (MODE == BA_FITTING);
     constexpr bool left_free = (MODE == BA_OVERLAP);
-    const int32_t *bottom_row = P.bnd + (size_t)(P.nsuper - 1) * P.bnd_stride;  // the last strip is the last wave of the last workgroup
+    // the last strip is the last wave of the last workgroup; its bottom row lies in HBM as {score, tag} granules
+    const int32_t *bottom_row = P.bnd + (size_t)(P.nsuper - 1) * P.bnd_stride * 2;
     // column stripes: columns are the stripe's own (1..m), column 0 belongs to the stripe on the left
     const int col0 = (int)P.col0;
     const int32_t *left_col = P.left_col;
@@ -436,7 +476,7 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
         i = P.start_i;
         j = P.start_j;
     } else if (MODE == BA_GLOBAL) {
-        cur = bottom_row[m - 1];
+        cur = bottom_row[2 * (m - 1)];
         bv = cur - g * (n + col0 + m);
     } else {
         // leftmost strict maximum of the true scores Hs(n, j) - g*j of the bottom row, from column 0
@@ -445,7 +485,7 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
         bv = first_stripe ? b_left * n : INT32_MIN;
         for (int c0 = 0; c0 < m; c0 += 64) {
             const int col = c0 + lane;  // 0-based array index = column col+1
-            const int hv = col < m ? bottom_row[col] : 0;
+            const int hv = col < m ? bottom_row[2 * col] : 0;
             int v = col < m ? hv - g * (col0 + col + 1) : INT32_MIN;
             int jj = col + 1, cc = hv;
 #pragma unroll
@@ -701,12 +741,13 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
     // 84 KB of (unused) dynamic LDS: at most one workgroup per CU -- each of its four strips has a SIMD to itself,
     // and it is the placement the sc1 hand-off was measured in (MI355X_MICROARCH.md, "Hand-offs measured with sc1
     // loads"); workgroups beyond the CU count queue up behind the ones they depend on
-    const size_t pad_lds = 84 * 1024;
+    const char *pe = getenv("BIOALIGN_LONG_PAD_KB");
+    const size_t pad_lds = (size_t)(pe ? atoi(pe) : 84) * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
     hipError_t e = hipSuccess;
     if (phases & BA_LONG_PHASE_DP) {
-        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K>), dim3(P.nsuper), dim3(64 * (BA_LONG_W + 2)), pad_lds, st, P);
+        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K>), dim3(P.nsuper), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (phases & BA_LONG_PHASE_WALK) {
@@ -721,6 +762,9 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
 template <int MODE>
 static hipError_t launch_long_mode(const BaLongParams &P, int T, int K, int phases, hipStream_t st)
 {
+    if (T == 1 && K == 2) return launch_long<MODE, 1, 2>(P, phases, st);
+    if (T == 1 && K == 4) return launch_long<MODE, 1, 4>(P, phases, st);
+    if (T == 1 && K == 8) return launch_long<MODE, 1, 8>(P, phases, st);
     if (T == 2 && K == 2) return launch_long<MODE, 2, 2>(P, phases, st);
     if (T == 2 && K == 4) return launch_long<MODE, 2, 4>(P, phases, st);
     if (T == 2 && K == 8) return launch_long<MODE, 2, 8>(P, phases, st);
@@ -730,14 +774,17 @@ static hipError_t launch_long_mode(const BaLongParams &P, int T, int K, int phas
     return hipErrorInvalidValue;
 }
 
-// rows per lane (T * K divides 32).  The critical path of one pair is about T * m + 2 * n cell latencies (a strip is
-// 64 * T rows, each strip starts about 2 * 64 steps after the one above), and its width is n / (64 * T) wavefronts:
-// short strips win until the wavefronts outnumber the SIMDs.  BIOALIGN_LONG_T=4 for experiments.
+// rows per lane (T * K divides 32).  One pair is latency-bound: a lone wavefront spends about 65 + 11 T cycles on a
+// step (measured, profiles/r02_notes.md: the serial chain DPP -> T dependent v_max3 and the waits around it, not the
+// issue slots), a strip of 64 T rows starts 63 + 16 steps after the one above, so the DP takes about
+// (m + 80 n / (64 T)) (65 + 11 T) cycles plus the HBM hops between workgroups: T = 2 and T = 4 come out the same at
+// 100k x 100k, and the traceback likes the taller strips.  BIOALIGN_LONG_T=1|2 for experiments.
 extern "C" int ba_long_rows_per_lane(int K)
 {
     (void)K;
     const char *e = getenv("BIOALIGN_LONG_T");
-    return (e && atoi(e) == 4) ? 4 : 2;
+    const int t = e ? atoi(e) : 0;
+    return (t == 1 || t == 2) ? t : 4;
 }
 // strips per workgroup
 extern "C" int ba_long_strips_per_group(void) { return BA_LONG_W; }

@@ -15,13 +15,14 @@ ap.add_argument("--m", type=int, default=100_000)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--mode", default="global")
 ap.add_argument("--oracle-prefix", type=int, default=20_000)
+ap.add_argument("--score-only", action="store_true", help="DP and end cell only (no walk): the DP kernel's own time")
 args = ap.parse_args()
 t0 = time.time()
 s1, o1, s2, o2 = synth.dna_pairs(1, args.n, args.m, config=5, sub=0.06, ins=0.02, dele=0.02)
 gen = time.time() - t0
 table, c1, c2 = synth.dna_table(1, -1)
 eng = _native.Engine([0])
-pb = _native.PackedBatch(s1, o1, s2, o2, args.mode, table, c1, c2, 1, 1)
+pb = _native.PackedBatch(s1, o1, s2, o2, args.mode, table, c1, c2, 1, 1, flags=_native.SCORE_ONLY if args.score_only else 0)
 best = None
 for r in range(args.reps):
     t0 = time.time()
@@ -30,6 +31,10 @@ for r in range(args.reps):
     if best is None or eng.last_kernel_ms < best[0]:
         best = (eng.last_kernel_ms, wall)
 cells = args.n * args.m
+if args.score_only:
+    print(json.dumps({"config": 5, "mode": args.mode, "n": args.n, "m": args.m, "cells": cells, "score": int(scores[0]), "score_only": True,
+                      "kernel_ms": round(best[0], 3), "kernel_gcups": round(cells / (best[0] * 1e-3) / 1e9, 1)}), flush=True)
+    sys.exit(0)
 a, l = int(toff[0]), int(tlen[0])
 x, y = t1[a:a + l], t2[a:a + l]
 gapc = ord("-")
