@@ -239,7 +239,7 @@ def run_rank(args):
     for mode, go, ge in passes:
         plans.append(eng.plan(_native.PackedBatch(s1, o1, s2, o2, mode, table, code1, code2, go, ge)))
     # several modes over the same pairs: the later passes read the packed copy the first pass made
-    if len(plans) > 1 and os.environ.get("BIOALIGN_BENCH_SHARE_PACK", "1") != "0":
+    if len(plans) > 1 and os.environ.get("BIOALIGN_BENCH_SHARE_PACK", "1") != "0" and os.environ.get("BIOALIGN_BENCH_STREAMS", "1") != "2":
         for pl in plans[1:]:
             pl.share_pack(plans[0])
     cells_per_pass = plans[0].cells
@@ -264,12 +264,17 @@ def run_rank(args):
             t_len=torch.empty(max(N, 1), dtype=torch.int64, device=dev),
         ))
     stream = torch.cuda.current_stream().cuda_stream
+    # experiment (BIOALIGN_BENCH_STREAMS=2): every pass on a stream of its own, so that the latency-bound traceback
+    # of one overlaps the VALU-bound DP of the other
+    multi = os.environ.get("BIOALIGN_BENCH_STREAMS", "1") == "2" and len(plans) > 1
+    side = [torch.cuda.Stream(device=dev) for _ in plans[1:]] if multi else []
 
     def step():
-        for plan, o in zip(plans, outs):
+        for k, (plan, o) in enumerate(zip(plans, outs)):
+            st = stream if (k == 0 or not multi) else side[k - 1].cuda_stream
             plan.run(d_s1.data_ptr(), d_o1.data_ptr(), d_s2.data_ptr(), d_o2.data_ptr(),
                      o["scores"].data_ptr(), o["t1"].data_ptr(), o["t2"].data_ptr(),
-                     o["t_off"].data_ptr(), o["t_len"].data_ptr(), stream)
+                     o["t_off"].data_ptr(), o["t_len"].data_ptr(), st)
 
     def barrier():
         torch.cuda.synchronize()

@@ -174,7 +174,7 @@ def AlignLocal(s1: bytes, s2: bytes, a, indelPenalty: int):
 
 def AlignPairLong(mode: str, s1: bytes, s2: bytes, a, indelPenalty: int):
     """AlignPair for ONE long pair: same result, computed by the intra-sequence wavefront
-    kernels (bioalign_long).  global / fitting / overlap, linear gap, <= 4 column symbols."""
+    kernels (bioalign_long).  global / fitting / overlap, linear gap, <= 64 distinct column symbols."""
     if mode not in _native.MODES:
         return -1, None, None
     sc, t1, t2 = _run_batch(mode, [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty, long=True)
@@ -186,7 +186,7 @@ def AlignGlobalLS(s1: bytes, s2: bytes, a, indelPenalty: int):
     (panics, alternate tie-breaks); this one returns exactly AlignGlobal's result, which is what
     its author's disabled test asks for (align_test.go:55-66).  Pairs of LONG_MIN_CELLS cells
     or more go to the long-mode kernels when their parameters allow it."""
-    if len(s1) * len(s2) >= LONG_MIN_CELLS and len(set(bytes(s2))) <= 4:
+    if len(s1) * len(s2) >= LONG_MIN_CELLS and len(set(bytes(s2))) <= 64:
         return AlignPairLong("global", s1, s2, a, indelPenalty)
     return AlignPair("global", s1, s2, a, indelPenalty)
 

@@ -1320,9 +1320,9 @@ int long_geometry(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t n, uin
                   std::vector<uint32_t> *rowprof)
 {
     const int g = in->gap_open;
-    if (in->nb > 4)
-        return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode packs the scores of one row symbol into one dword: "
-                                                "at most 4 distinct column symbols (got %d)", in->nb);
+    if (in->nb > 64)
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode keeps a strip profile of 256 bytes per column symbol and wavefront "
+                                                "in LDS: at most 64 distinct column symbols (got %d)", in->nb);
     int wmax = 0;
     for (int i = 0; i < in->na * in->nb; ++i) {
         const int64_t v = (int64_t)in->score_table[i] + 2 * g;
@@ -1338,15 +1338,12 @@ int long_geometry(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t n, uin
         return ctx->fail(BIOALIGN_EUNSUPPORTED, "pair too long for 32-bit working scores");
     *K_out = K;
     *T_out = ba_long_rows_per_lane(K);
-    rowprof->assign(in->na + 1, 0x80808080u);
-    for (int a = 0; a < in->na; ++a) {
-        uint32_t w = 0;
-        for (int b = 0; b < 4; ++b) {
-            const int v = b < in->nb ? in->score_table[a * in->nb + b] + 2 * g : -128;
-            w |= (uint32_t)(uint8_t)(int8_t)v << (8 * b);
-        }
-        (*rowprof)[a] = w;
-    }
+    // signed bytes [na + 1][nb], packed into dwords for the upload; the padding row scores -128 against everything
+    const size_t bytes = (size_t)(in->na + 1) * in->nb;
+    rowprof->assign((bytes + 3) / 4, 0x80808080u);
+    int8_t *tab = reinterpret_cast<int8_t *>(rowprof->data());
+    for (int a = 0; a < in->na; ++a)
+        for (int b = 0; b < in->nb; ++b) tab[(size_t)a * in->nb + b] = (int8_t)(in->score_table[a * in->nb + b] + 2 * g);
     return 0;
 }
 

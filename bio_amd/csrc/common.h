@@ -106,7 +106,7 @@ struct BaLongParams {
     uint32_t strips;               // ceil(n / (64*T)), bottom aligned
     uint32_t nsuper;               // workgroups = ceil(strips / strips per workgroup); the last strip is the last wave of the last one
     uint32_t words_per_strip;      // residue dwords per lane per strip = ceil((m + 63) / CPD)
-    const uint32_t *rowprof;       // [na + 1] dwords: bytes w(a, b) + 2g for b = 0..3; entry na = padding (-128)
+    const uint32_t *rowprof;       // signed bytes [na + 1][nb]: w(a, b) + 2g; row na = padding (-128 against everything)
     const uint8_t *code1, *code2;  // [256] byte -> dense code
     int pad_code;                  // = na
     int gap;

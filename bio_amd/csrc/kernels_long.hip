@@ -25,13 +25,11 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 #include "device_helpers.h"
 
-// the cell's substitution score: 0 = v_bfe_i32 + v_add, 1 = one v_dot4c_i32_i8 with the one-hot column symbol
-#ifndef BA_LONG_CELL
-#define BA_LONG_CELL 0
-#endif
 #define BA_LONG_FINAL 0x7fffffffu   // progress word: every column has been handed over
 #define BA_LONG_POISON 0x80000000u  // progress word, top bit: a wait ran out upstream; do not wait for this strip
 #ifndef BA_LONG_W
@@ -75,29 +73,24 @@ struct BaLongGeom {
 
 // What one strip (wavefront) keeps in LDS for itself, dwords.
 struct BaLongWaveLds {
-    uint32_t ohw[128];   // column symbols in the form the cell wants them (see ba_long_step), window of two 64-column
+    uint32_t ohw[128];   // column symbols as byte offsets into a lane's strip profile (4 * code), window of two 64-column
                          // blocks [previous | current]: lane l at step k of a block reads slot 64 + k - l
     int32_t dummy[128];  // where the lanes other than 63 put their (not yet final) bottom-row values
 };
 
 #define BA_LONG_RING (BA_LONG_RB * 64)  // columns a hand-over ring holds
 
-// One step of one lane: T cells of one column.
+// One step of one lane: T cells of one column.  `pw` holds the substitution scores of the lane's T rows against this
+// column's symbol, one signed byte per row (from the lane's strip profile in LDS): the byte is an SDWA operand of the add.
 // CHECK: the lane may be outside its column range (start-up and drain of the skew) and must then keep its state.
 template <int T, int K, bool CHECK>
-__device__ __forceinline__ void ba_long_step(int (&h)[T], const uint32_t (&prow)[T], uint32_t &acc, int top, int diag0,
-                                             uint32_t oh, bool active)
+__device__ __forceinline__ void ba_long_step(int (&h)[T], uint32_t &acc, int top, int diag0, uint32_t pw, bool active)
 {
     int up = top, diag = diag0;
 #pragma unroll
     for (int r = 0; r < T; ++r) {
         const int left = h[r];
-#if BA_LONG_CELL == 1
-        // the score is the dot product of the row's four score bytes with the column symbol's one-hot bytes
-        const int d = __builtin_amdgcn_sdot4((int)prow[r], (int)oh, diag, false);
-#else
-        const int d = diag + __builtin_amdgcn_sbfe((int)prow[r], oh, 8);  // oh = 8 * the column symbol's code
-#endif
+        const int d = diag + ba_sbyte(pw, r);
         int hn = ba_max3(up, left, d);
         if (CHECK) hn = active ? hn : left;
         acc = __builtin_amdgcn_alignbit((uint32_t)hn, acc, K);
@@ -135,6 +128,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
 {
     using G = BaLongGeom<T, K>;
     constexpr int RS = G::RS, CPD = G::CPD, W = BA_LONG_W, RING = BA_LONG_RING;
+    extern __shared__ __align__(16) uint32_t dyn_lds[];  // strip profiles: [wave][column symbol][lane] dwords, then padding
     __shared__ uint32_t code2s[64];  // byte -> code of the column side, packed
     __shared__ BaLongWaveLds wl[W];
     __shared__ int32_t rings[W + 1][RING];
@@ -264,13 +258,24 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     const int32_t *left_col = P.left_col;  // column stripes: handed over by the stripe to the left
     auto first_col = [&](int i) { return left_col ? left_col[max(i, 0)] : b_left * max(i, 0); };
     int h[T];
-    uint32_t prow[T];
+    // strip profile: prof[b][lane] = the scores of my T rows against column symbol b, one signed byte per row
+    // (score + 2g; rows above the matrix carry the padding code: -128 against everything)
+    uint32_t *prof = dyn_lds + (size_t)w * P.nb * 64 + lane;
+    {
+        int code[T];
 #pragma unroll
-    for (int r = 0; r < T; ++r) {
-        const int i = i0 + lane * T + r + 1;
-        const int code = i >= 1 ? (int)P.code1[P.s1[i - 1]] : P.pad_code;
-        prow[r] = P.rowprof[code];
-        h[r] = first_col(i);
+        for (int r = 0; r < T; ++r) {
+            const int i = i0 + lane * T + r + 1;
+            code[r] = i >= 1 ? (int)P.code1[P.s1[i - 1]] : P.pad_code;
+            h[r] = first_col(i);
+        }
+        const int8_t *tab = reinterpret_cast<const int8_t *>(P.rowprof);  // [na + 1][nb] signed bytes
+        for (int b = 0; b < P.nb; ++b) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int r = 0; r < T; ++r) word |= (uint32_t)(uint8_t)tab[code[r] * P.nb + b] << (8 * r);
+            prof[b * 64] = word;
+        }
     }
     uint32_t *resid = P.resid + (size_t)s * P.words_per_strip * 64 + lane;
 
@@ -283,13 +288,9 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
 
     const uint32_t *oh_me = L.ohw + 64 - lane;  // my window slot for step 0 of a block
 
-    auto load_symbols = [&](int b) -> uint32_t {  // the column symbol of column b*64 + lane (0-based), as the cell wants it
+    auto load_symbols = [&](int b) -> uint32_t {  // column b*64 + lane (0-based): where its scores lie in a lane's profile
         const int col = b * 64 + lane;
-#if BA_LONG_CELL == 1
-        return col < m ? (1u << (8 * (uint32_t)code2[P.s2[col]])) : 0u;
-#else
-        return col < m ? 8u * (uint32_t)code2[P.s2[col]] : 0u;
-#endif
+        return col < m ? 256u * (uint32_t)code2[P.s2[col]] : 0u;  // (byte offset of prof[code][0]; beyond the matrix: anything valid)
     };
     uint32_t ohnext = load_symbols(0);
     uint32_t pseen = 0;  // columns of the row above known to be final
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
         int32_t *wp = (lane == 63) ? ring_out + ((t0 - 63) & (RING - 1)) : L.dummy + lane;
         int32_t *wp63 = (lane == 63) ? ring_out + (t0 & (RING - 1)) : L.dummy + lane;
 
-        uint32_t ohA[16], ohB[16];
+        uint32_t ohA[16], ohB[16], pwA[16], pwB[16];
         int tinA[16], tinB[16];
         // columns j*16 .. j*16+15 of the row above must be final (columns >= m never are: nobody reads them)
         auto need_cols = [&](int j) -> uint32_t { return (uint32_t)min(t0 + j * 16 + 16, m); };
@@ -331,12 +332,17 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
                 tin[k] = tin_base[j * 16 + k];
             }
         };
-        auto compute = [&](const uint32_t (&oh)[16], const int (&tin)[16], int j) {
+        // the scores of my rows against the 16 column symbols of a sub-block: one dword of my strip profile each
+        auto scores = [&](uint32_t (&pw)[16], const uint32_t (&oh)[16]) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) pw[k] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(prof) + oh[k]);
+        };
+        auto compute = [&](const uint32_t (&pw)[16], const int (&tin)[16], int j) {
             if (steady) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int top = ba_wave_shr1(tin[k], bottom);
-                    ba_long_step<T, K, false>(h, prow, acc, top, topprev, oh[k], true);
+                    ba_long_step<T, K, false>(h, acc, top, topprev, pw[k], true);
                     topprev = top;
                     bottom = h[T - 1];
                     ba_lds_store((j * 16 + k == 63) ? wp63 : wp + j * 16 + k, bottom);
@@ -349,7 +355,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
                     if (t < total_steps) {
                         const int top = ba_wave_shr1(tin[k], bottom);
                         const bool active = (t >= lane) && (t - lane < m);
-                        ba_long_step<T, K, true>(h, prow, acc, top, topprev, oh[k], active);
+                        ba_long_step<T, K, true>(h, acc, top, topprev, pw[k], active);
                         topprev = top;
                         bottom = h[T - 1];
                         ba_lds_store((j * 16 + k == 63) ? wp63 : wp + j * 16 + k, bottom);
@@ -364,30 +370,34 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
             else
                 publish(prog_out, (uint32_t)fin);
         };
-        // sub-block j with its inputs in (oh, tin); the inputs of sub-block j+1 are fetched into (ohn, tinn) before the
-        // steps when the row above is known to be far enough, after them (waiting) otherwise
-        auto stage = [&](const uint32_t (&oh)[16], const int (&tin)[16], uint32_t (&ohn)[16], int (&tinn)[16], int j, bool more) {
+        // sub-block j with its inputs in (pw, tin); the inputs of sub-block j+1 are fetched into (ohn, tinn) before the
+        // steps when the row above is known to be far enough, after them (waiting) otherwise, and its scores after the
+        // steps (their addresses are the symbols just fetched)
+        auto stage = [&](const uint32_t (&pw)[16], const int (&tin)[16], uint32_t (&ohn)[16], int (&tinn)[16],
+                         uint32_t (&pwn)[16], int j, bool more) {
             // (compiler barriers, not fences: what orders the ring reads behind the counter read is the LDS itself,
             // which carries out one wavefront's operations in the order they were issued)
             asm volatile("" ::: "memory");
             const uint32_t fresh = ld(prog_in);  // (in flight during the steps)
             const bool early = more && pseen >= need_cols(j + 1);
             if (early) fetch(ohn, tinn, j + 1);
-            compute(oh, tin, j);
+            compute(pw, tin, j);
             pseen = max(pseen, fresh);
             if (more && !early) {
                 if (pseen < need_cols(j + 1)) pseen = max(pseen, wait_lds(prog_in, need_cols(j + 1)));
                 asm volatile("" ::: "memory");
                 fetch(ohn, tinn, j + 1);
             }
+            if (more) scores(pwn, ohn);
         };
         if (pseen < need_cols(0)) pseen = max(pseen, wait_lds(prog_in, need_cols(0)));
         asm volatile("" ::: "memory");
         fetch(ohA, tinA, 0);
-        stage(ohA, tinA, ohB, tinB, 0, true);
-        stage(ohB, tinB, ohA, tinA, 1, true);
-        stage(ohA, tinA, ohB, tinB, 2, true);
-        stage(ohB, tinB, ohA, tinA, 3, false);
+        scores(pwA, ohA);
+        stage(pwA, tinA, ohB, tinB, pwB, 0, true);
+        stage(pwB, tinB, ohA, tinA, pwA, 1, true);
+        stage(pwA, tinA, ohB, tinB, pwB, 2, true);
+        stage(pwB, tinB, ohA, tinA, pwA, 3, false);
         // ---- end of the block ----
         publish(cons_in, (uint32_t)min(t0 + 64, m));  // (the values read are in registers or used up)
         {
@@ -741,8 +751,9 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
     // 84 KB of (unused) dynamic LDS: at most one workgroup per CU -- each of its four strips has a SIMD to itself,
     // and it is the placement the sc1 hand-off was measured in (MI355X_MICROARCH.md, "Hand-offs measured with sc1
     // loads"); workgroups beyond the CU count queue up behind the ones they depend on
-    const char *pe = getenv("BIOALIGN_LONG_PAD_KB");
-    const size_t pad_lds = (size_t)(pe ? atoi(pe) : 84) * 1024;
+    // the strip profiles of the workgroup's waves (256 bytes per column symbol and wave), padded to 84 KB
+    const size_t prof_lds = (size_t)BA_LONG_W * (size_t)P.nb * 256;
+    const size_t pad_lds = std::max<size_t>(prof_lds, 84 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
     hipError_t e = hipSuccess;

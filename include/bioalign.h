@@ -191,7 +191,7 @@ int bioalign_plan_share_pack(bioalign_plan *plan, const bioalign_plan *packed_by
  * wavefront, strips pipelined through HBM -- which is what a single long pair needs
  * (AlignGlobalLS, align_linear.go:9, on inputs the per-lane batch kernels would crawl through;
  * AlignPair "global" / "fitting" / "overlap", align_pair.go:3, likewise).  Linear gaps, at most
- * 4 distinct column symbols; anything else answers BIOALIGN_EUNSUPPORTED.  Runs on the first
+ * 64 distinct column symbols; anything else answers BIOALIGN_EUNSUPPORTED.  Runs on the first
  * device of the context -- unless the traceback matrix of a pair (up to one byte per cell) would
  * not fit that device and the context holds several: the matrix is then cut into column
  * stripes, one per device in turn, each stripe's last column handed to the next by a

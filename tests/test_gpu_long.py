@@ -68,8 +68,20 @@ def test_long_unsupported_fails_loudly():
     with pytest.raises(bio_amd._native.BioAlignError) as e:
         bio_amd.AlignPairLong("local", b"ACGT" * 10, b"ACG" * 10, bio_amd.MatchAligner(1, -1), 1)
     assert e.value.code == bio_amd._native.EUNSUPPORTED
-    with pytest.raises(bio_amd._native.BioAlignError):
-        bio_amd.AlignPairLong("global", b"ARNDC" * 10, b"ARNDCQ" * 10, bio_amd.Blosum62, 5)  # 6 column symbols
+
+
+@pytest.mark.parametrize("mode", ["global", "fitting", "overlap"])
+def test_long_protein_alphabets(mode):
+    # any alphabet up to 64 column symbols: the strip profile of a lane lies in LDS (20 symbols, 8 residue bits here)
+    s1, o1, s2, o2 = synth.protein_pairs(1, 3100, 3300, config=3, first=7)
+    x, y = s1.tobytes(), s2.tobytes()
+    assert bio_amd.AlignPairLong(mode, x, y, bio_amd.Blosum62, 5) == O.AlignPair(mode, x, y, O.Blosum62(), 5)
+    rng = random.Random(21)
+    alpha = b"ARNDCQEGHILKMFPSTWYV"
+    for n, m in [(1, 1), (70, 300), (515, 130), (260, 777)]:
+        x = bytes(rng.choice(alpha) for _ in range(n))
+        y = bytes(rng.choice(alpha) for _ in range(m))
+        assert bio_amd.AlignPairLong(mode, x, y, bio_amd.Pam250, 7) == O.AlignPair(mode, x, y, O.Pam250(), 7), (mode, n, m)
 
 
 @pytest.mark.parametrize("stripes", [2, 3, 5])
