@@ -62,6 +62,9 @@ EXPORTS = (
     "bioalign_stripe_destroy",
     "bioalign_stripe_rows",
     "bioalign_stripe_dp",
+    "bioalign_stripe_blocks",
+    "bioalign_stripe_block_rows",
+    "bioalign_stripe_dp_block",
     "bioalign_stripe_end_cell",
     "bioalign_stripe_walk",
 )
@@ -184,6 +187,12 @@ def lib():
         L.bioalign_stripe_rows.argtypes = [C.c_void_p]
         L.bioalign_stripe_dp.restype = C.c_int
         L.bioalign_stripe_dp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bioalign_stripe_blocks.restype = C.c_uint32
+        L.bioalign_stripe_blocks.argtypes = [C.c_void_p]
+        L.bioalign_stripe_block_rows.restype = C.c_int
+        L.bioalign_stripe_block_rows.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.bioalign_stripe_dp_block.restype = C.c_int
+        L.bioalign_stripe_dp_block.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.bioalign_stripe_end_cell.restype = C.c_int
         L.bioalign_stripe_end_cell.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]
         L.bioalign_stripe_walk.restype = C.c_int
@@ -448,6 +457,22 @@ class Stripe:
     def dp(self, d_left_col, d_right_col):
         """Device addresses (ints or None) of rows+1 int32 each; returns when the stripe's DP is done."""
         rc = lib().bioalign_stripe_dp(self._h, d_left_col, d_right_col)
+        if rc != 0:
+            self.engine._raise(rc)
+
+    def blocks(self):
+        """Row blocks of the stripe's DP: [(row_begin, row_end), ...], the same in every stripe of the pair."""
+        out = []
+        for k in range(int(lib().bioalign_stripe_blocks(self._h))):
+            lo, hi = C.c_uint64(), C.c_uint64()
+            if lib().bioalign_stripe_block_rows(self._h, k, C.byref(lo), C.byref(hi)) != 0:
+                self.engine._raise(EINVAL)
+            out.append((lo.value, hi.value))
+        return out
+
+    def dp_block(self, k, d_left_rows, d_right_rows):
+        """Row block k (in order): device addresses of row_end - row_begin int32 each; returns when the block is done."""
+        rc = lib().bioalign_stripe_dp_block(self._h, int(k), d_left_rows, d_right_rows)
         if rc != 0:
             self.engine._raise(rc)
 

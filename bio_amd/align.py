@@ -21,7 +21,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _native
-from .subst_matrix import score_table
+from .subst_matrix import cooccurrence, score_table
 
 GapSymbol = ord("-")  # align.go:3
 
@@ -99,12 +99,16 @@ def pack_sequences(seqs):
 LONG_MIN_CELLS = 1 << 24  # AlignGlobalLS hands pairs of at least this many cells to the long-mode kernels
 
 
-def _run_batch(mode, s1s, s2s, a, gap_open, gap_extend, score_only=False, long=False):
+def _run_batch(mode, s1s, s2s, a, gap_open, gap_extend, score_only=False, long=False, scale=1):
     if mode not in _native.MODES:
         raise KeyError(mode)
     d1, o1 = pack_sequences(s1s)
     d2, o2 = pack_sequences(s2s)
-    table, code1, code2 = score_table(a, np.unique(d1).tolist(), np.unique(d2).tolist())
+    # (a Score that raises fails the batch only if some pair puts those two bytes against each other, as in the reference)
+    table, code1, code2 = score_table(a, np.unique(d1).tolist(), np.unique(d2).tolist(),
+                                      needed=cooccurrence(d1, o1, d2, o2) if len(s1s) > 1 else None)
+    if scale != 1:
+        table = table * np.int32(scale)  # dyadic penalties: everything in units of 1 / scale
     pb = _native.PackedBatch(d1, o1, d2, o2, mode, table, code1, code2, gap_open, gap_extend,
                              gap_symbol=_gap(), flags=_native.SCORE_ONLY if score_only else 0)
     scores, t1, t2, t_off, t_len = engine().batch(pb, long=long)
@@ -191,11 +195,27 @@ def AlignGlobalLS(s1: bytes, s2: bytes, a, indelPenalty: int):
     return AlignPair("global", s1, s2, a, indelPenalty)
 
 
+def _dyadic_scale(*vals, max_shift=6):
+    """The smallest power of two that turns every value into a whole number, or None."""
+    for e in range(max_shift + 1):
+        if all(float(v) * (1 << e) == int(float(v) * (1 << e)) for v in vals):
+            return 1 << e
+    return None
+
+
 def AlignGlobalAffine(s1: bytes, s2: bytes, a, gapOpenPenalty: float, gapExtendPenalty: float):
-    """align_affine.go:12-167: float64 score, integer arithmetic underneath.  The
-    penalties must be whole numbers (the GPU path is exact integer Gotoh)."""
+    """align_affine.go:12-167: float64 penalties and score, integer arithmetic underneath.
+
+    Fractional penalties are not truncated: penalties that are multiples of 1/2, 1/4 ... 1/64 run
+    in units of that fraction (substitution scores and penalties times 2^e, exact integer Gotoh,
+    score divided back), which is what the reference's float64 arithmetic computes exactly --
+    every sum it forms is a small multiple of 2^-e, so no rounding and the same comparisons.
+    Any other fraction (0.1, 1/3) makes the reference's result depend on float64 rounding along
+    the path; that cannot be reproduced bit for bit in integers and is refused loudly."""
     go, ge = float(gapOpenPenalty), float(gapExtendPenalty)
-    if go != int(go) or ge != int(ge):
-        raise ValueError("AlignGlobalAffine on the GPU path needs integer-valued penalties")
-    sc, t1, t2 = _run_batch("global", [bytes(s1)], [bytes(s2)], a, int(go), int(ge))
-    return float(sc[0]), t1[0], t2[0]
+    scale = _dyadic_scale(go, ge)
+    if scale is None:
+        raise ValueError("AlignGlobalAffine on the GPU path needs penalties that are multiples of 1/64 "
+                         f"(got open {go!r}, extend {ge!r}): the kernels are exact integer Gotoh")
+    sc, t1, t2 = _run_batch("global", [bytes(s1)], [bytes(s2)], a, int(go * scale), int(ge * scale), scale=scale)
+    return sc[0] / scale, t1[0], t2[0]

@@ -1220,6 +1220,7 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     P.nsuper = (uint32_t)nsuper;
     P.bnd_stride = (uint32_t)((m + 15) / 16 * 16);
     P.epoch = 1;
+    P.wg_begin = P.wg_count = 0;
     P.s1 = d_s1.as<uint8_t>();
     P.s2 = d_s2.as<uint8_t>();
     P.n = (uint32_t)n;
@@ -1301,6 +1302,10 @@ struct bioalign_stripe {
     int mode = 0, T = 8, K = 2;
     uint64_t n = 0, c0 = 0, m = 0, m_total = 0, wps = 0, strips = 0, nsuper = 0;
     bool traces = true, dp_done = false;
+    // row blocks: block k = workgroups [blk[k], blk[k+1]) = rows [blk_row[k], blk_row[k+1]) of column 0 .. (row 0 in block 0)
+    std::vector<uint32_t> blk;
+    std::vector<uint64_t> blk_row;
+    uint32_t blocks_done = 0;
     DevBuf s1, s2, prof, c1, c2, bnd, res, misc, t1, t2, ops, left, right;
     hipStream_t st = nullptr;
     hipEvent_t done = nullptr;
@@ -1370,6 +1375,27 @@ int stripe_init(bioalign_stripe &x, bioalign_ctx *ctx, int dev, const bioalign_b
     x.strips = (n + rs - 1) / rs;
     x.nsuper = (x.strips + ba_long_strips_per_group() - 1) / ba_long_strips_per_group();
     x.wps = (x.m + 63 + cpd - 1) / cpd;
+    {
+        // Row blocks: the DP of a stripe runs block by block, each block one launch over some of the
+        // workgroups, so that a stripe can start on a block as soon as its left neighbour has handed that block's
+        // rows of its last column over, while the neighbour goes on with the next block.  Same blocks in every
+        // stripe of a pair (they depend on n alone).  BIOALIGN_STRIPE_BLOCKS sets their number (default 8).
+        const uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>(env_u64("BIOALIGN_STRIPE_BLOCKS", 8), x.nsuper));
+        const uint64_t per = (x.nsuper + want - 1) / want;
+        const uint64_t W = (uint64_t)ba_long_strips_per_group(), pad = x.nsuper * W - x.strips;
+        x.blk.clear();
+        x.blk_row.clear();
+        for (uint64_t b0 = 0; b0 < x.nsuper; b0 += per) {
+            x.blk.push_back((uint32_t)b0);
+            // first row of the first strip of workgroup b0 (strip b0 * W - pad, rows above the matrix belong to block 0)
+            const int64_t s_first = (int64_t)(b0 * W) - (int64_t)pad;
+            const int64_t row = s_first <= 0 ? 0 : (int64_t)n - (int64_t)(x.strips - (uint64_t)s_first) * (int64_t)rs + 1;
+            x.blk_row.push_back((uint64_t)std::max<int64_t>(row, 0));
+        }
+        x.blk.push_back((uint32_t)x.nsuper);
+        x.blk_row.push_back(n + 1);
+        x.blk_row[0] = 0;
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->devices[dev]));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&x.st, hipStreamNonBlocking));
     HIP_TRY(ctx, hipEventCreateWithFlags(&x.done, hipEventDisableTiming));
@@ -1399,6 +1425,7 @@ int stripe_init(bioalign_stripe &x, bioalign_ctx *ctx, int dev, const bioalign_b
     P.nsuper = (uint32_t)x.nsuper;
     P.bnd_stride = (uint32_t)((x.m + 15) / 16 * 16);
     P.epoch = 1;
+    P.wg_begin = P.wg_count = 0;
     P.words_per_strip = (uint32_t)x.wps;
     P.rowprof = x.prof.as<uint32_t>();
     P.code1 = x.c1.as<uint8_t>();
@@ -1428,15 +1455,31 @@ int stripe_init(bioalign_stripe &x, bioalign_ctx *ctx, int dev, const bioalign_b
     return 0;
 }
 
-// queues the stripe's DP on its stream; a stripe that is not the first one reads its left column (x.left) first
-int stripe_dp(bioalign_stripe &x)
+// queues row block k of the stripe's DP on its stream (blocks in order); the rows of x.left that the block reads --
+// [blk_row[k], blk_row[k+1]) and the row above them -- must be in place on that stream by then
+int stripe_dp_block(bioalign_stripe &x, uint32_t k)
 {
     bioalign_ctx *ctx = x.ctx;
+    if (k != x.blocks_done || k + 1 >= x.blk.size()) return ctx->fail(BIOALIGN_EINVAL, "stripe: row blocks run once each, in order");
     HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
-    hipError_t le = ba_launch_long(x.P, x.mode, x.T, x.K, BA_LONG_PHASE_DP, x.st);
+    BaLongParams Pk = x.P;
+    Pk.wg_begin = x.blk[k];
+    Pk.wg_count = x.blk[k + 1] - x.blk[k];
+    hipError_t le = ba_launch_long(Pk, x.mode, x.T, x.K, BA_LONG_PHASE_DP, x.st);
     if (le != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "long-mode DP kernel failed: %s", hipGetErrorString(le));
-    HIP_TRY(ctx, hipEventRecord(x.done, x.st));
-    x.dp_done = true;
+    x.blocks_done = k + 1;
+    if (x.blocks_done + 1 == x.blk.size()) {
+        HIP_TRY(ctx, hipEventRecord(x.done, x.st));
+        x.dp_done = true;
+    }
+    return 0;
+}
+
+// queues the whole DP of the stripe on its stream; a stripe that is not the first one reads its left column (x.left)
+int stripe_dp(bioalign_stripe &x)
+{
+    for (uint32_t k = x.blocks_done; k + 1 < x.blk.size(); ++k)
+        if (int rc = stripe_dp_block(x, k)) return rc;
     return 0;
 }
 
@@ -1508,20 +1551,42 @@ int long_pair_striped(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_re
         if ((rc = stripe_init(S[q], ctx, q % D, in, p, m * (uint64_t)q / G, m * (uint64_t)(q + 1) / G))) return rc;
 
     const auto t_begin = std::chrono::steady_clock::now();
-    // DP, stripe after stripe: the neighbour's last column comes in over the device-to-device copy
-    for (int q = 0; q < G; ++q) {
-        bioalign_stripe &x = S[q];
-        if (q > 0) {
-            bioalign_stripe &l = S[q - 1];
-            HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
-            HIP_TRY(ctx, hipStreamWaitEvent(x.st, l.done, 0));
-            if (ctx->devices[l.dev] == ctx->devices[x.dev])
-                HIP_TRY(ctx, hipMemcpyAsync(x.left.p, l.right.p, (n + 1) * 4, hipMemcpyDeviceToDevice, x.st));
-            else
-                HIP_TRY(ctx, hipMemcpyPeerAsync(x.left.p, ctx->devices[x.dev], l.right.p, ctx->devices[l.dev], (n + 1) * 4, x.st));
+    // DP as a pipeline over row blocks: stripe q runs block r once stripe q-1 has finished block r and
+    // those rows of its last column have come over (a device-to-device copy, xGMI between GPUs; stream-ordered behind
+    // an event, no host round trip), while stripe q-1 goes on with block r+1.  Every stripe has its own stream.
+    const uint32_t R = (uint32_t)S[0].blk.size() - 1;
+    std::vector<hipEvent_t> ev((size_t)G * R, nullptr);
+    struct EvGuard {
+        std::vector<hipEvent_t> &v;
+        ~EvGuard()
+        {
+            for (hipEvent_t e : v)
+                if (e) (void)hipEventDestroy(e);
         }
-        if ((rc = stripe_dp(x))) return rc;
-    }
+    } ev_guard{ev};
+    // Queued by anti-diagonals of the (stripe, block) grid: the blocks of one diagonal depend on the diagonal before it
+    // alone, so a hardware queue that several of these streams share never holds a block in front of one it waits for.
+    for (uint32_t d = 0; d + 1 < R + (uint32_t)G; ++d)
+        for (int q = 0; q < G; ++q) {
+            if ((uint32_t)q > d || d - (uint32_t)q >= R) continue;
+            const uint32_t r = d - (uint32_t)q;
+            bioalign_stripe &x = S[q];
+            HIP_TRY(ctx, hipSetDevice(ctx->devices[x.dev]));
+            if (q > 0) {
+                bioalign_stripe &l = S[q - 1];
+                const uint64_t lo = x.blk_row[r], cnt = x.blk_row[r + 1] - lo;
+                HIP_TRY(ctx, hipStreamWaitEvent(x.st, ev[(size_t)(q - 1) * R + r], 0));
+                int32_t *dst = x.left.as<int32_t>() + lo;
+                const int32_t *src = l.right.as<int32_t>() + lo;
+                if (ctx->devices[l.dev] == ctx->devices[x.dev])
+                    HIP_TRY(ctx, hipMemcpyAsync(dst, src, cnt * 4, hipMemcpyDeviceToDevice, x.st));
+                else
+                    HIP_TRY(ctx, hipMemcpyPeerAsync(dst, ctx->devices[x.dev], src, ctx->devices[l.dev], cnt * 4, x.st));
+            }
+            if ((rc = stripe_dp_block(x, r))) return rc;
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ev[(size_t)q * R + r], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventRecord(ev[(size_t)q * R + r], x.st));
+        }
     // end cell: global = the last cell of the last stripe; fitting / overlap = leftmost strict maximum of the
     // bottom row over all stripes (align_pair.go:169-182): every stripe reports its own
     int end_stripe = G - 1;
@@ -1677,6 +1742,35 @@ extern "C" int bioalign_stripe_dp(bioalign_stripe *x, const int32_t *d_left_col,
     if (rc) return rc;
     if (d_right_col)
         HIP_TRY(ctx, hipMemcpyAsync(d_right_col, x->right.p, (x->n + 1) * 4, hipMemcpyDeviceToDevice, x->st));
+    HIP_TRY(ctx, hipStreamSynchronize(x->st));
+    return 0;
+}
+
+extern "C" uint32_t bioalign_stripe_blocks(const bioalign_stripe *x) { return x ? (uint32_t)x->blk.size() - 1 : 0; }
+
+extern "C" int bioalign_stripe_block_rows(const bioalign_stripe *x, uint32_t block, uint64_t *row_begin, uint64_t *row_end)
+{
+    if (!x || !row_begin || !row_end || block + 1 >= x->blk.size()) return BIOALIGN_EINVAL;
+    *row_begin = x->blk_row[block];
+    *row_end = x->blk_row[block + 1];
+    return 0;
+}
+
+extern "C" int bioalign_stripe_dp_block(bioalign_stripe *x, uint32_t block, const int32_t *d_left_rows, int32_t *d_right_rows)
+{
+    if (!x) return BIOALIGN_EINVAL;
+    bioalign_ctx *ctx = x->ctx;
+    if (block + 1 >= x->blk.size()) return ctx->fail(BIOALIGN_EINVAL, "stripe: no such row block");
+    if ((x->c0 > 0) != (d_left_rows != nullptr))
+        return ctx->fail(BIOALIGN_EINVAL, "stripe: the left column is required for every stripe but the first, and only there");
+    const uint64_t lo = x->blk_row[block], cnt = x->blk_row[block + 1] - lo;
+    HIP_TRY(ctx, hipSetDevice(ctx->devices[x->dev]));
+    if (d_left_rows)
+        HIP_TRY(ctx, hipMemcpyAsync(x->left.as<int32_t>() + lo, d_left_rows, cnt * 4, hipMemcpyDeviceToDevice, x->st));
+    int rc = stripe_dp_block(*x, block);
+    if (rc) return rc;
+    if (d_right_rows)
+        HIP_TRY(ctx, hipMemcpyAsync(d_right_rows, x->right.as<int32_t>() + lo, cnt * 4, hipMemcpyDeviceToDevice, x->st));
     HIP_TRY(ctx, hipStreamSynchronize(x->st));
     return 0;
 }

@@ -105,6 +105,8 @@ struct BaLongParams {
     uint32_t n, m;
     uint32_t strips;               // ceil(n / (64*T)), bottom aligned
     uint32_t nsuper;               // workgroups = ceil(strips / strips per workgroup); the last strip is the last wave of the last one
+    uint32_t wg_begin, wg_count;   // this launch runs workgroups [wg_begin, wg_begin + wg_count) (0, 0: all): a row block of the matrix;
+                                   // the workgroups above must have run (their bottom rows lie in bnd)
     uint32_t words_per_strip;      // residue dwords per lane per strip = ceil((m + 63) / CPD)
     const uint32_t *rowprof;       // signed bytes [na + 1][nb]: w(a, b) + 2g; row na = padding (-128 against everything)
     const uint8_t *code1, *code2;  // [256] byte -> dense code

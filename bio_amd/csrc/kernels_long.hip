@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     __shared__ uint32_t fail_s;          // a wait has run out somewhere in this workgroup
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int S = blockIdx.x;
+    const int S = (int)(blockIdx.x + P.wg_begin);
     const int n = (int)P.n, m = (int)P.m, g = P.gap;
     const int strips = (int)P.strips;
     const int pad = (int)P.nsuper * W - strips;
@@ -758,7 +758,8 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
     hipError_t e = hipSuccess;
     if (phases & BA_LONG_PHASE_DP) {
-        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K>), dim3(P.nsuper), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+        const uint32_t wgs = P.wg_count ? P.wg_count : P.nsuper - P.wg_begin;
+        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K>), dim3(wgs), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (phases & BA_LONG_PHASE_WALK) {
@@ -804,6 +805,7 @@ extern "C" int ba_long_strips_per_group(void) { return BA_LONG_W; }
 extern "C" hipError_t ba_launch_long(const BaLongParams &P, int mode, int T, int K, int phases, hipStream_t st)
 {
     if (P.n == 0 || P.m == 0 || P.strips == 0 || (uint64_t)P.nsuper * BA_LONG_W < P.strips) return hipErrorInvalidValue;
+    if ((uint64_t)P.wg_begin + P.wg_count > P.nsuper || P.wg_begin >= P.nsuper) return hipErrorInvalidValue;
     switch (mode) {
     case BA_GLOBAL: return launch_long_mode<BA_GLOBAL>(P, T, K, phases, st);
     case BA_FITTING: return launch_long_mode<BA_FITTING>(P, T, K, phases, st);

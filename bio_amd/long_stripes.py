@@ -5,8 +5,10 @@ holding columns [r*m/W, (r+1)*m/W) and all rows on its own GPU (bioalign_stripe_
 include/bioalign.h).  The only data that crosses GPUs:
 
   1. DP: the last column of a stripe -- n+1 int32 working-space scores -- goes to the rank on
-     its right: point-to-point send / recv (backend nccl = RCCL over xGMI on a GPU node; gloo
-     in the CPU test).  No collective is involved in the data path.
+     its right in ROW BLOCKS (the stripe's blocks(): a few thousand rows each, the same on every
+     rank): point-to-point send / recv per block (backend nccl = RCCL over xGMI on a GPU node;
+     gloo in the CPU test), so that rank r works on block k while rank r-1 works on block k+1.
+     No collective is involved in the data path.
   2. End cell: every rank offers the best end cell of its stretch of the bottom row
      (align_pair.go:169-182; global: the last rank's last cell, align.go:123-124); one
      all_gather of four integers per rank picks the leftmost best.
@@ -17,8 +19,8 @@ include/bioalign.h).  The only data that crosses GPUs:
 
 This is the process-group form of what bioalign_long does across the devices of one context
 (bio_amd/csrc/api.cpp: long_pair_striped).  At the size of BASELINE.json's configs[4]
-(100k x 100k) one GPU is latency-bound, not capacity-bound, and the stripes' DP phases run one
-after the other: stripes are for matrices whose traceback residues do not fit one GPU.
+(100k x 100k) one GPU is latency-bound, not capacity-bound: stripes are for matrices whose
+traceback residues do not fit one GPU.
 """
 from __future__ import annotations
 
@@ -43,15 +45,22 @@ class GpuStripe:
         self.pb = _native.PackedBatch(d1, o1, d2, o2, mode, tbl, c1, c2, gap_open=gap, gap_extend=gap)
         self.stripe = _native.Stripe(self.engine, self.pb, col_begin, col_end)
         self.rows, self.width = self.stripe.rows, self.stripe.width
+        self._blocks = self.stripe.blocks()
 
-    def dp(self, left):
+    def blocks(self):
+        return self._blocks
+
+    def dp_block(self, k, left):
+        """Row block k of the DP: `left` = the block's rows of the left neighbour's last column (None for the first
+        stripe); returns the block's rows of this stripe's last column."""
         torch = self._torch
-        right = torch.empty(self.rows + 1, dtype=torch.int32, device=self.dev)
+        lo, hi = self._blocks[k]
+        right = torch.empty(hi - lo, dtype=torch.int32, device=self.dev)
         left_dev = None
         if left is not None:
             left_dev = left.to(self.dev).contiguous()
         torch.cuda.synchronize(self.dev)  # the library works on its own stream
-        self.stripe.dp(left_dev.data_ptr() if left_dev is not None else None, right.data_ptr())
+        self.stripe.dp_block(k, left_dev.data_ptr() if left_dev is not None else None, right.data_ptr())
         return right.to(self.xdev)
 
     def end_cell(self):
@@ -72,8 +81,9 @@ def align_long_striped(mode: str, s1: bytes, s2: bytes, a, gap: int, *, group=No
     matrix spread over the ranks of `group`.  Every rank calls this with the same arguments; rank `dst` returns
     (score, t1, t2) as AlignPairLong does, the others (score, None, None).
 
-    make_stripe(mode, s1, s2, a, gap, col_begin, col_end, xdev) -> object with rows, width, dp(left) -> right,
-    end_cell() -> (true score, j_local, score), walk(i, j_local) -> (piece1, piece2, exit_i, exit_j).  The
+    make_stripe(mode, s1, s2, a, gap, col_begin, col_end, xdev) -> object with rows, width, blocks() -> row ranges,
+    dp_block(k, left rows) -> right rows, end_cell() -> (true score, j_local, score), walk(i, j_local) ->
+    (piece1, piece2, exit_i, exit_j).  The
     default is the GPU stripe; there is no CPU fallback (the CPU test injects its own restatement).
     """
     import torch
@@ -97,15 +107,16 @@ def align_long_striped(mode: str, s1: bytes, s2: bytes, a, gap: int, *, group=No
     G = len(bounds) - 1
     stripe = make_stripe(mode, s1, s2, a, gap, bounds[rank], bounds[rank + 1], xdev) if rank < G else None
 
-    # 1. DP, left to right
+    # 1. DP, left to right, row block by row block: while this rank works on block k its left neighbour is on k+1
     if stripe is not None:
-        left = None
-        if rank > 0:
-            left = torch.empty(n + 1, dtype=torch.int32, device=xdev)
-            dist.recv(left, src=peer(rank - 1), group=group)
-        right = stripe.dp(left)
-        if rank + 1 < G:
-            dist.send(right.contiguous(), dst=peer(rank + 1), group=group)
+        for k, (lo, hi) in enumerate(stripe.blocks()):
+            left = None
+            if rank > 0:
+                left = torch.empty(hi - lo, dtype=torch.int32, device=xdev)
+                dist.recv(left, src=peer(rank - 1), group=group)
+            right = stripe.dp_block(k, left)
+            if rank + 1 < G:
+                dist.send(right.contiguous(), dst=peer(rank + 1), group=group)
 
     # 2. the end cell: leftmost strict maximum over the stripes' offers (global: the last stripe's)
     offer = [0, 0, 0, 0]

@@ -109,13 +109,18 @@ Y -3  0 -4 -4  7 -5  0 -1 -4 -1 -2 -2 -5 -4 -4 -3 -3 -2  0 10
 """)
 
 
-def score_table(a, bytes1, bytes2):
+def score_table(a, bytes1, bytes2, needed=None):
     """Materialises an Aligner for the GPU.
 
     bytes1 / bytes2: the distinct bytes that occur on the s1 / s2 side of the batch.
     Calls a.Score(x, y) exactly once per (s1 byte, s2 byte) pair, argument order
-    (s1 byte, s2 byte) as align.go:113; symmetry is not assumed; an exception from
-    Score propagates like the reference's panic.
+    (s1 byte, s2 byte) as align.go:113; symmetry is not assumed.  An exception from
+    Score propagates like the reference's panic -- unless `needed` is given: the
+    reference scores (s1[i], s2[j]) inside one pair only, so a batch whose pairs never
+    put x against y must not fail because Score(x, y) would (an Aligner that panics on
+    foreign bytes, subst_matrix.go:15-17).  `needed(x, y) -> bool` says whether some
+    pair of the batch holds x on its s1 side and y on its s2 side; it is asked only
+    for cells whose Score raised, and those that no pair needs are left at 0.
     Returns (table[na, nb] int32, code1[256] uint8, code2[256] uint8).
     """
     b1 = sorted(set(bytes1))
@@ -130,7 +135,31 @@ def score_table(a, bytes1, bytes2):
         code2[y] = j
     for i, x in enumerate(b1):
         for j, y in enumerate(b2):
-            table[i, j] = a.Score(x, y)
+            try:
+                table[i, j] = a.Score(x, y)
+            except Exception:
+                if needed is None or needed(x, y):
+                    raise
     if table.size and (table.max() > 2**31 - 1 or table.min() < -(2**31)):
         raise OverflowError("Aligner scores do not fit 32 bits")
     return table.astype(np.int32), code1, code2
+
+
+def cooccurrence(d1, o1, d2, o2):
+    """needed(x, y) for score_table: does some pair p hold byte x in s1[p] and byte y in s2[p]?  Built on first use
+    (one pass over the batch), so batches whose Aligner never raises pay nothing."""
+    state = {}
+
+    def needed(x, y):
+        if "m" not in state:
+            n = len(o1) - 1
+            has1 = np.zeros((n, 256), dtype=bool)
+            has2 = np.zeros((n, 256), dtype=bool)
+            if len(d1):
+                has1[np.repeat(np.arange(n), np.diff(o1).astype(np.int64)), d1] = True
+            if len(d2):
+                has2[np.repeat(np.arange(n), np.diff(o2).astype(np.int64)), d2] = True
+            state["m"] = (has1.astype(np.int32).T @ has2.astype(np.int32)) > 0
+        return bool(state["m"][x, y])
+
+    return needed

@@ -226,6 +226,15 @@ bioalign_stripe *bioalign_stripe_create(bioalign_ctx *ctx, int device_index, con
 void bioalign_stripe_destroy(bioalign_stripe *stripe);
 uint64_t bioalign_stripe_rows(const bioalign_stripe *stripe);
 int bioalign_stripe_dp(bioalign_stripe *stripe, const int32_t *d_left_col, int32_t *d_right_col);
+/* The stripe's DP in row blocks, so that the stripes of a pair overlap: block k covers rows
+ * [row_begin, row_end) of column 0 .. -- the same rows in every stripe of the pair -- and is one launch; the stripe on
+ * the right may run block k as soon as it has these rows of this stripe's last column, while this stripe goes on with
+ * block k+1.  dp_block: d_left_rows / d_right_rows are device arrays of row_end - row_begin int32 (the block's rows
+ * of the neighbour's last column in, of this stripe's last column out; NULL as for bioalign_stripe_dp).  Blocks run
+ * once each, in order; bioalign_stripe_dp is all of them. */
+uint32_t bioalign_stripe_blocks(const bioalign_stripe *stripe);
+int bioalign_stripe_block_rows(const bioalign_stripe *stripe, uint32_t block, uint64_t *row_begin, uint64_t *row_end);
+int bioalign_stripe_dp_block(bioalign_stripe *stripe, uint32_t block, const int32_t *d_left_rows, int32_t *d_right_rows);
 int bioalign_stripe_end_cell(bioalign_stripe *stripe, int64_t *true_score, uint64_t *j_local, int64_t *score);
 int bioalign_stripe_walk(bioalign_stripe *stripe, uint64_t i, uint64_t j_local, uint8_t *t1, uint8_t *t2,
                          uint64_t *len, uint64_t *exit_i, uint64_t *exit_j);

@@ -110,11 +110,16 @@ def test_align_global_affine_score_is_the_references():
     for _ in range(40):
         x = bytes(rng.choice(alpha) for _ in range(rng.randrange(1, 40)))
         y = bytes(rng.choice(alpha) for _ in range(rng.randrange(1, 40)))
-        go, ge = rng.choice([(11.0, 1.0), (5.0, 2.0), (7.0, 0.0)])
+        # whole and fractional penalties (multiples of 1/64 run in units of the fraction, nothing is truncated)
+        go, ge = rng.choice([(11.0, 1.0), (5.0, 2.0), (7.0, 0.0), (2.5, 0.5), (10.75, 1.25), (3.5, 3.5)])
         sc, t1, t2 = bio_amd.AlignGlobalAffine(x, y, bio_amd.Blosum62, go, ge)
         assert isinstance(sc, float)
         assert sc == O.AffineGlobalScoreF64(x, y, O.Blosum62(), go, ge)
         assert bytes(b for b in t1 if b != ord("-")) == x and bytes(b for b in t2 if b != ord("-")) == y
+    # a fraction whose unit makes the scores outgrow the int8 profile is refused by the library, not rounded
+    with pytest.raises(bio_amd._native.BioAlignError) as e:
+        bio_amd.AlignGlobalAffine(b"ACDDE", b"ACE", bio_amd.Blosum62, 1.015625, 0.5)
+    assert e.value.code == bio_amd._native.EUNSUPPORTED
     # the input on which the reference's own traceback goes wrong: score as written, trace correct
     sc, t1, t2 = bio_amd.AlignGlobalAffine(b"ACDDE", b"ACE", bio_amd.Blosum62, 5, 1)
     assert sc == O.AffineGlobalScoreF64(b"ACDDE", b"ACE", O.Blosum62(), 5.0, 1.0)

@@ -153,7 +153,34 @@ def test_errors_that_never_reach_the_device():
     with pytest.raises(ValueError):
         bio_amd.AlignPairBatch("global", [b"A"], [], a, 1)
     with pytest.raises(ValueError):
-        bio_amd.AlignGlobalAffine(b"AC", b"AC", a, 2.5, 1)
+        bio_amd.AlignGlobalAffine(b"AC", b"AC", a, 0.1, 1)  # not a multiple of 1/64: float64 rounding decides in the reference
+    from bio_amd.align import _dyadic_scale
+    assert _dyadic_scale(11.0, 1.0) == 1 and _dyadic_scale(2.5, 1) == 2 and _dyadic_scale(0.75, 0.25) == 4
+    assert _dyadic_scale(1 / 3, 1) is None and _dyadic_scale(0.1, 0.5) is None
+
+
+def test_score_table_fails_only_for_cells_some_pair_needs():
+    # subst_matrix.go:15-17: Score panics on a byte outside the alphabet.  The reference scores (s1[i], s2[j]) inside one
+    # pair only, so a batch must not fail on byte pairs that never meet.
+    from bio_amd.subst_matrix import cooccurrence, score_table
+
+    class Strict:
+        def Score(self, x, y):
+            if chr(x) in "ACGT" and chr(y) in "ACGT":
+                return 1 if x == y else -1
+            if chr(x) in "xy" and chr(y) in "xy":
+                return 2 if x == y else -2
+            raise IndexError("index out of range")
+
+    d1, o1 = bio_amd.pack_sequences([b"ACGT", b"xyx"])
+    d2, o2 = bio_amd.pack_sequences([b"AGT", b"yy"])
+    with pytest.raises(IndexError):
+        score_table(Strict(), np.unique(d1).tolist(), np.unique(d2).tolist())
+    t, c1, c2 = score_table(Strict(), np.unique(d1).tolist(), np.unique(d2).tolist(), needed=cooccurrence(d1, o1, d2, o2))
+    assert t[c1[ord("A")], c2[ord("A")]] == 1 and t[c1[ord("x")], c2[ord("y")]] == -2 and t[c1[ord("A")], c2[ord("y")]] == 0
+    d2b, o2b = bio_amd.pack_sequences([b"AGy", b"yy"])  # now a pair does put A against y
+    with pytest.raises(IndexError):
+        score_table(Strict(), np.unique(d1).tolist(), np.unique(d2b).tolist(), needed=cooccurrence(d1, o1, d2b, o2b))
 
 
 def test_packed_batch_validation():

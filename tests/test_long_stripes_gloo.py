@@ -37,21 +37,29 @@ class PyStripe:
     def _w(self, x, y):
         return self.match if x == y else self.mismatch
 
-    def dp(self, left):
+    def blocks(self):
+        # row blocks of 16 rows (row 0 in the first one), the same on every rank
+        n = self.rows
+        cuts = [0] + list(range(17, n + 1, 16)) + [n + 1]
+        return [(cuts[k], cuts[k + 1]) for k in range(len(cuts) - 1)]
+
+    def dp_block(self, k, left):
         n, w, g = self.rows, self.width, self.g
-        H = [[0] * (w + 1) for _ in range(n + 1)]
-        for i in range(n + 1):
+        lo, hi = self.blocks()[k]
+        if k == 0:
+            self.H = [[0] * (w + 1) for _ in range(n + 1)]
+            for j in range(1, w + 1):
+                self.H[0][j] = 0 if self.mode == "fitting" else -g * (self.c0 + j)  # align_pair.go:110-112, 158, 187
+        H = self.H
+        for i in range(lo, hi):
             if left is None:
                 H[i][0] = 0 if self.mode == "overlap" else -g * i      # align_pair.go:113, 131, 159, 188
             else:
-                H[i][0] = int(left[i]) - g * (i + self.c0)
-        for j in range(1, w + 1):
-            H[0][j] = 0 if self.mode == "fitting" else -g * (self.c0 + j)  # align_pair.go:110-112, 158, 187
-        for i in range(1, n + 1):
+                H[i][0] = int(left[i - lo]) - g * (i + self.c0)
+        for i in range(max(lo, 1), hi):
             for j in range(1, w + 1):
                 H[i][j] = max(H[i - 1][j] - g, H[i][j - 1] - g, H[i - 1][j - 1] + self._w(self.s1[i - 1], self.s2[j - 1]))
-        self.H = H
-        return torch.tensor([H[i][w] + g * (i + self.c0 + w) for i in range(n + 1)], dtype=torch.int32, device=self.xdev)
+        return torch.tensor([H[i][w] + g * (i + self.c0 + w) for i in range(lo, hi)], dtype=torch.int32, device=self.xdev)
 
     def end_cell(self):
         n, w, H = self.rows, self.width, self.H
