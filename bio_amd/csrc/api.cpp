@@ -1216,7 +1216,7 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     HIP_TRY(ctx, hipMemsetAsync(d_bnd.p, 0, nsuper * ((m + 15) / 16 * 16) * 8 + 256, st));  // tag 0: not handed over yet
     HIP_TRY(ctx, hipMemsetAsync(d_misc.p, 0, 64, st));
 
-    BaLongParams P;
+    BaLongParams P{};
     P.nsuper = (uint32_t)nsuper;
     P.bnd_stride = (uint32_t)((m + 15) / 16 * 16);
     P.epoch = 1;
@@ -1306,10 +1306,10 @@ struct bioalign_stripe {
     std::vector<uint32_t> blk;
     std::vector<uint64_t> blk_row;
     uint32_t blocks_done = 0;
-    DevBuf s1, s2, prof, c1, c2, bnd, res, misc, t1, t2, ops, left, right;
+    DevBuf s1, s2, prof, c1, c2, bnd, res, misc, t1, t2, ops, left, right, rgran;
     hipStream_t st = nullptr;
     hipEvent_t done = nullptr;
-    BaLongParams P;
+    BaLongParams P{};
     ~bioalign_stripe()
     {
         if (ctx) (void)hipSetDevice(ctx->devices[dev]);
@@ -1551,6 +1551,64 @@ int long_pair_striped(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_re
         if ((rc = stripe_init(S[q], ctx, q % D, in, p, m * (uint64_t)q / G, m * (uint64_t)(q + 1) / G))) return rc;
 
     const auto t_begin = std::chrono::steady_clock::now();
+    // All stripes on one device: ONE launch holds the workgroups of every stripe, and a strip starts as soon as the strip
+    // at its height in the stripe to its left has finished (tagged granules in HBM, as between workgroups): the DP is
+    // the same wavefront as the unstriped one.  BIOALIGN_STRIPE_MERGED=0 keeps the host-driven row blocks below.
+    bool merged = D == 1 && G > 1 && env_u64("BIOALIGN_STRIPE_MERGED", 1) != 0;
+    uint64_t total_wgs = 0;
+    for (int q = 0; q < G; ++q) total_wgs += S[q].nsuper;
+    if (total_wgs > 0x7fffffffull) merged = false;
+    DevBuf d_multi, d_order;
+    if (merged) {
+        HIP_TRY(ctx, hipSetDevice(ctx->devices[S[0].dev]));
+        for (int q = 0; q + 1 < G; ++q) {
+            if ((rc = S[q].rgran.alloc(ctx, (n + 1) * 8))) return rc;
+            HIP_TRY(ctx, hipMemsetAsync(S[q].rgran.p, 0, (n + 1) * 8, S[0].st));  // tag 0: not handed over yet
+        }
+        std::vector<BaLongParams> multi(G);
+        for (int q = 0; q < G; ++q) {
+            BaLongParams Pq = S[q].P;
+            Pq.right_col = nullptr;
+            Pq.left_gran = q > 0 ? S[q - 1].rgran.as<unsigned long long>() : nullptr;
+            Pq.right_gran = q + 1 < G ? S[q].rgran.as<unsigned long long>() : nullptr;
+            multi[q] = Pq;
+        }
+        // workgroups in the order they can start: (columns left of the stripe) + (strips above) * (steps a strip lags)
+        struct Wg {
+            uint64_t key;
+            uint32_t q, s;
+        };
+        std::vector<Wg> wg;
+        wg.reserve(total_wgs);
+        const uint64_t lag = 80ull * (uint64_t)ba_long_strips_per_group();
+        for (int q = 0; q < G; ++q)
+            for (uint64_t s = 0; s < S[q].nsuper; ++s) wg.push_back({S[q].c0 + s * lag, (uint32_t)q, (uint32_t)s});
+        std::sort(wg.begin(), wg.end(), [](const Wg &a, const Wg &b) {
+            return a.key != b.key ? a.key < b.key : a.q != b.q ? a.q < b.q : a.s < b.s;
+        });
+        std::vector<uint2> order(wg.size());
+        for (size_t k = 0; k < wg.size(); ++k) order[k] = make_uint2(wg[k].q, wg[k].s);
+        if ((rc = d_multi.alloc(ctx, multi.size() * sizeof(BaLongParams))) || (rc = d_order.alloc(ctx, order.size() * sizeof(uint2)))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(d_multi.p, multi.data(), multi.size() * sizeof(BaLongParams), hipMemcpyHostToDevice, S[0].st));
+        HIP_TRY(ctx, hipMemcpyAsync(d_order.p, order.data(), order.size() * sizeof(uint2), hipMemcpyHostToDevice, S[0].st));
+        HIP_TRY(ctx, hipStreamSynchronize(S[0].st));  // (the sources are locals)
+        BaLongParams P0 = S[0].P;
+        P0.multi = d_multi.as<BaLongParams>();
+        P0.order = d_order.as<uint2>();
+        P0.wg_begin = 0;
+        P0.wg_count = (uint32_t)total_wgs;
+        hipError_t le = ba_launch_long(P0, S[0].mode, S[0].T, S[0].K, BA_LONG_PHASE_DP, S[0].st);
+        if (le != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "long-mode DP kernel failed: %s", hipGetErrorString(le));
+        HIP_TRY(ctx, hipEventRecord(S[0].done, S[0].st));
+        for (int q = 0; q < G; ++q) {
+            S[q].blocks_done = (uint32_t)S[q].blk.size() - 1;
+            S[q].dp_done = true;
+            if (q > 0) {
+                HIP_TRY(ctx, hipStreamWaitEvent(S[q].st, S[0].done, 0));
+                HIP_TRY(ctx, hipEventRecord(S[q].done, S[q].st));
+            }
+        }
+    }
     // DP as a pipeline over row blocks: stripe q runs block r once stripe q-1 has finished block r and
     // those rows of its last column have come over (a device-to-device copy, xGMI between GPUs; stream-ordered behind
     // an event, no host round trip), while stripe q-1 goes on with block r+1.  Every stripe has its own stream.
@@ -1566,7 +1624,7 @@ int long_pair_striped(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_re
     } ev_guard{ev};
     // Queued by anti-diagonals of the (stripe, block) grid: the blocks of one diagonal depend on the diagonal before it
     // alone, so a hardware queue that several of these streams share never holds a block in front of one it waits for.
-    for (uint32_t d = 0; d + 1 < R + (uint32_t)G; ++d)
+    for (uint32_t d = 0; !merged && d + 1 < R + (uint32_t)G; ++d)
         for (int q = 0; q < G; ++q) {
             if ((uint32_t)q > d || d - (uint32_t)q >= R) continue;
             const uint32_t r = d - (uint32_t)q;

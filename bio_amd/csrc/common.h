@@ -136,6 +136,14 @@ struct BaLongParams {
     int32_t *right_col;            // [n + 1] out: Hs(i, col0 + m) (null: not wanted)
     int start_i, start_j;          // walk: start from this cell instead of looking for the end cell (start_j < 0: look for it)
     int scan_only;                 // walk: find the end cell of this stripe's bottom row, report it, stop
+    // several stripes of one pair in ONE launch (all on this device): workgroup b of the grid is workgroup order[b].y of
+    // stripe order[b].x and takes its parameters from multi[order[b].x].  A stripe's last column goes to its right
+    // neighbour as tagged granules {score, tag} (right_gran, [n + 1], zeroed before the launch); the neighbour's strips
+    // wait for the granules of their own rows (left_gran) and copy the scores to their plain left_col for the walk.
+    const BaLongParams *multi;
+    const uint2 *order;
+    const unsigned long long *left_gran;
+    unsigned long long *right_gran;
 };
 
 // FASTA text -> concatenated sequences + offsets (kernels_fasta.hip)

@@ -123,8 +123,12 @@ __device__ __forceinline__ void ba_long_step(int (&h)[T], uint32_t &acc, int top
 // rest of the workgroup's bottom row goes out with a poisoned tag, which fails the workgroups below at once, and the
 // host reports the run as failed.  (The cross-workgroup wait assumes what the status word guards: a workgroup's
 // predecessor is resident or finished, which holds while workgroups are dispatched in index order.)
-template <int MODE, int T, int K>
-__global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLongParams P)
+//
+// MULTI: the grid holds the workgroups of several column stripes of one pair (P0.multi / P0.order); the workgroups
+// are ordered by the time they can start, which keeps every workgroup behind the two it waits for -- the one above it
+// in its own stripe and the one at its height in the stripe to its left.
+template <int MODE, int T, int K, bool MULTI>
+__global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLongParams P0)
 {
     using G = BaLongGeom<T, K>;
     constexpr int RS = G::RS, CPD = G::CPD, W = BA_LONG_W, RING = BA_LONG_RING;
@@ -137,7 +141,17 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     __shared__ uint32_t fail_s;          // a wait has run out somewhere in this workgroup
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int S = (int)(blockIdx.x + P.wg_begin);
+    BaLongParams Pm;
+    int S_;
+    if (MULTI) {
+        const uint2 o = P0.order[blockIdx.x];
+        Pm = P0.multi[o.x];
+        S_ = (int)o.y;
+    } else {
+        S_ = (int)(blockIdx.x + P0.wg_begin);
+    }
+    const BaLongParams &P = MULTI ? Pm : P0;
+    const int S = S_;
     const int n = (int)P.n, m = (int)P.m, g = P.gap;
     const int strips = (int)P.strips;
     const int pad = (int)P.nsuper * W - strips;
@@ -256,11 +270,15 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     // carry the padding code and reproduce row 0 (see kernels.hip)
     const int i0 = n - (strips - s) * RS;
     const int32_t *left_col = P.left_col;  // column stripes: handed over by the stripe to the left
-    auto first_col = [&](int i) { return left_col ? left_col[max(i, 0)] : b_left * max(i, 0); };
+    auto first_col = [&](int i) {
+        if (MULTI && P.left_gran) return 0;  // (comes through the granules below)
+        return left_col ? left_col[max(i, 0)] : b_left * max(i, 0);
+    };
     int h[T];
     // strip profile: prof[b][lane] = the scores of my T rows against column symbol b, one signed byte per row
     // (score + 2g; rows above the matrix carry the padding code: -128 against everything)
     uint32_t *prof = dyn_lds + (size_t)w * P.nb * 64 + lane;
+    int left_top = first_col(i0);  // Hs(i0, 0): the diagonal of my first row's first column
     {
         int code[T];
 #pragma unroll
@@ -268,6 +286,40 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
             const int i = i0 + lane * T + r + 1;
             code[r] = i >= 1 ? (int)P.code1[P.s1[i - 1]] : P.pad_code;
             h[r] = first_col(i);
+        }
+        if (MULTI && P.left_gran) {
+            // my rows of the left neighbour's last column, as soon as its strip at my height has finished (bounded)
+            const unsigned long long *lg = P.left_gran;
+            bool bad = false;
+            for (int spin = 0;; ++spin) {
+                bool ok = true;
+                const unsigned long long g0 = __hip_atomic_load(lg + max(i0, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (uint32_t)(g0 >> 32) == epoch;
+                bad = bad || (uint32_t)(g0 >> 32) == (epoch | BA_LONG_POISON);
+                left_top = (int)(uint32_t)g0;
+#pragma unroll
+                for (int r = 0; r < T; ++r) {
+                    const int i = i0 + lane * T + r + 1;
+                    const unsigned long long gr = __hip_atomic_load(lg + max(i, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (uint32_t)(gr >> 32) == epoch;
+                    bad = bad || (uint32_t)(gr >> 32) == (epoch | BA_LONG_POISON);
+                    h[r] = (int)(uint32_t)gr;
+                }
+                if (__all(ok)) break;
+                if (__any(bad) || spin >= (1 << 22) || ld(&fail_s)) {
+                    st(&fail_s, 1u);
+                    break;
+                }
+                for (int z = 0; z < min(spin + 1, 4); ++z) __builtin_amdgcn_s_sleep(8);
+            }
+            // the plain copy the walk reads (P.left_col is this stripe's own buffer)
+            int32_t *lp = const_cast<int32_t *>(P.left_col);
+#pragma unroll
+            for (int r = 0; r < T; ++r) {
+                const int i = i0 + lane * T + r + 1;
+                if (i >= 1) lp[i] = h[r];
+            }
+            if (s == 0 && lane == 0) lp[0] = left_top;
         }
         const int8_t *tab = reinterpret_cast<const int8_t *>(P.rowprof);  // [na + 1][nb] signed bytes
         for (int b = 0; b < P.nb; ++b) {
@@ -283,7 +335,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     int bottom = h[T - 1];
     // score above my first row in the column BEFORE my current one (the diagonal of my first row);
     // before the first step that is column 0 of the row above: my upper neighbour's initial bottom
-    int topprev = ba_wave_shr1(first_col(i0), bottom);
+    int topprev = ba_wave_shr1(left_top, bottom);
     uint32_t acc = 0;
 
     const uint32_t *oh_me = L.ohw + 64 - lane;  // my window slot for step 0 of a block
@@ -429,6 +481,16 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
             if (i >= 1) P.right_col[i] = h[r];
         }
         if (s == 0 && lane == 0) P.right_col[0] = b_top * (col0 + m);
+    }
+    if (MULTI && P.right_gran) {
+        const unsigned long long tag = (unsigned long long)(failed ? (epoch | BA_LONG_POISON) : epoch) << 32;
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            const int i = i0 + lane * T + r + 1;
+            if (i >= 1) __hip_atomic_store(P.right_gran + i, tag | (uint32_t)h[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (s == 0 && lane == 0)
+            __hip_atomic_store(P.right_gran, tag | (uint32_t)(b_top * (col0 + m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -754,12 +816,18 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
     // the strip profiles of the workgroup's waves (256 bytes per column symbol and wave), padded to 84 KB
     const size_t prof_lds = (size_t)BA_LONG_W * (size_t)P.nb * 256;
     const size_t pad_lds = std::max<size_t>(prof_lds, 84 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
     hipError_t e = hipSuccess;
-    if (phases & BA_LONG_PHASE_DP) {
+    if ((phases & BA_LONG_PHASE_DP) && P.multi) {
+        // several stripes in one launch: wg_count = the workgroups of all of them (P.order)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
+        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K, true>), dim3(P.wg_count), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    } else if (phases & BA_LONG_PHASE_DP) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
         const uint32_t wgs = P.wg_count ? P.wg_count : P.nsuper - P.wg_begin;
-        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K>), dim3(wgs), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K, false>), dim3(wgs), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (phases & BA_LONG_PHASE_WALK) {
@@ -805,7 +873,11 @@ extern "C" int ba_long_strips_per_group(void) { return BA_LONG_W; }
 extern "C" hipError_t ba_launch_long(const BaLongParams &P, int mode, int T, int K, int phases, hipStream_t st)
 {
     if (P.n == 0 || P.m == 0 || P.strips == 0 || (uint64_t)P.nsuper * BA_LONG_W < P.strips) return hipErrorInvalidValue;
-    if ((uint64_t)P.wg_begin + P.wg_count > P.nsuper || P.wg_begin >= P.nsuper) return hipErrorInvalidValue;
+    if (P.multi) {
+        if (!P.order || P.wg_count == 0 || phases != BA_LONG_PHASE_DP) return hipErrorInvalidValue;
+    } else if ((uint64_t)P.wg_begin + P.wg_count > P.nsuper || P.wg_begin >= P.nsuper) {
+        return hipErrorInvalidValue;
+    }
     switch (mode) {
     case BA_GLOBAL: return launch_long_mode<BA_GLOBAL>(P, T, K, phases, st);
     case BA_FITTING: return launch_long_mode<BA_FITTING>(P, T, K, phases, st);

@@ -84,13 +84,17 @@ def test_long_protein_alphabets(mode):
         assert bio_amd.AlignPairLong(mode, x, y, bio_amd.Pam250, 7) == O.AlignPair(mode, x, y, O.Pam250(), 7), (mode, n, m)
 
 
+@pytest.mark.parametrize("merged", ["1", "0"])
 @pytest.mark.parametrize("stripes", [2, 3, 5])
 @pytest.mark.parametrize("mode", ["global", "fitting", "overlap"])
-def test_long_column_stripes(mode, stripes, monkeypatch):
+def test_long_column_stripes(mode, stripes, merged, monkeypatch):
     # the matrix cut into column stripes, every stripe with its own residues, the last column of a
     # stripe handed to its right neighbour, the walk handed on at every stripe's column 0.  One GPU here, so all
-    # stripes sit on the same device (the copy between devices becomes a plain device copy); same answers.
+    # stripes sit on the same device: merged = one launch over all stripes, the column handed over strip by strip on the
+    # device; not merged = the host-driven row blocks that several devices use (copies become plain device copies).
     monkeypatch.setenv("BIOALIGN_LONG_STRIPES", str(stripes))
+    monkeypatch.setenv("BIOALIGN_STRIPE_MERGED", merged)
+    monkeypatch.setenv("BIOALIGN_STRIPE_BLOCKS", "3")
     a, oa = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
     shapes = [(5, 7), (70, 64), (130, 129), (513, 190), (700, 900), (1100, 300), (30, 1000), (600, 3)]
     for k, (n, m) in enumerate(shapes):
@@ -116,6 +120,30 @@ def test_long_column_stripes_paths_along_the_borders(monkeypatch):
     x, y = _pair(900, 1300, 77)
     for mode in ("global", "fitting", "overlap"):
         assert bio_amd.AlignPairLong(mode, x, y, a, 3) == O.AlignPair(mode, x, y, oa, 3)
+
+
+def test_long_column_stripes_20k_merged_and_row_blocks(monkeypatch):
+    # many workgroups per stripe: the start-time order of the merged launch and the row blocks of the host-driven one
+    from bio_amd import _native, synth
+    s1, o1, s2, o2 = synth.dna_pairs(1, 20_000, 20_000, config=5, sub=0.06, ins=0.02, dele=0.02)
+    table, c1, c2 = synth.dna_table(1, -1)
+    col, _ = O.lastColumnScores(s1.tobytes(), s2.tobytes(), O.MatchAligner(1, -1), -1)
+    eng = bio_amd.align.engine()
+    monkeypatch.setenv("BIOALIGN_LONG_STRIPES", "8")
+    ref = None
+    for merged in ("1", "0"):
+        monkeypatch.setenv("BIOALIGN_STRIPE_MERGED", merged)
+        sc, t1, t2, toff, tlen = eng.long(_native.PackedBatch(s1, o1, s2, o2, "global", table, c1, c2, 1, 1))
+        a, l = int(toff[0]), int(tlen[0])
+        got = (int(sc[0]), t1[a:a + l].tobytes(), t2[a:a + l].tobytes())
+        assert got[0] == int(col[-1])
+        assert got[1].replace(b"-", b"") == s1.tobytes() and got[2].replace(b"-", b"") == s2.tobytes()
+        ref = ref or got
+        assert got == ref
+    monkeypatch.delenv("BIOALIGN_LONG_STRIPES")
+    sc, t1, t2, toff, tlen = eng.long(_native.PackedBatch(s1, o1, s2, o2, "global", table, c1, c2, 1, 1))
+    a, l = int(toff[0]), int(tlen[0])
+    assert (int(sc[0]), t1[a:a + l].tobytes(), t2[a:a + l].tobytes()) == ref  # the unstriped run gives the same traces
 
 
 def test_long_column_stripes_two_devices(monkeypatch):

@@ -56,6 +56,38 @@ __global__ void __launch_bounds__(256) op_kernel(int *out, int seed, unsigned lo
             if (OP == 29) OPK("v_cmp_gt_i32 vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc");
             if (OP == 30) OPK("v_xor_b32 %0, %0, %1");
             if (OP == 31) OPK("v_min_i32 %0, %0, %1");
+            if (OP == 32) OPK("v_dot4_i32_i8 %0, %1, %2, %0");
+            if (OP == 33) OPK("v_dot4c_i32_i8 %0, %1, %2");
+            if (OP == 34) OPK("v_sub_co_u32 %0, vcc, %0, %1");
+            if (OP == 35) OPK("v_add_u16 %0, %0, %1");
+            if (OP == 36) OPK("v_sub_u16 %0, %0, %1");
+            if (OP == 37) OPK("v_max_u16 %0, %0, %1");
+            if (OP == 38) OPK("v_min_i16 %0, %0, %1");
+            if (OP == 39) OPK("v_lshlrev_b32 %0, 1, %0");
+            if (OP == 40) OPK("v_lshrrev_b32 %0, 1, %0");
+            if (OP == 41) OPK("v_ashrrev_i32 %0, 1, %0");
+            if (OP == 42) OPK("v_or_b32 %0, %0, %1");
+            if (OP == 43) OPK("v_lshl_or_b32 %0, %0, 1, %1");
+            if (OP == 44) OPK("v_and_or_b32 %0, %0, %1, %2");
+            if (OP == 45) OPK("v_bfi_b32 %0, %0, %1, %2");
+            if (OP == 46) OPK("v_sub_u32_e64 %0, %0, %1 clamp");
+            if (OP == 47) OPK("v_mad_u32_u24 %0, %0, %1, %2");
+            if (OP == 48) OPK("v_mul_u32_u24 %0, %0, %1");
+            if (OP == 49) OPK("v_mad_u16 %0, %0, %1, %2");
+            if (OP == 50) OPK("v_alignbyte_b32 %0, %0, %1, 1");
+            if (OP == 51) OPK("v_add_u16_sdwa %0, sext(%1), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD");
+            if (OP == 52) OPK("v_max_i16_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD");
+            if (OP == 53) OPK("v_add_u32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf");
+            if (OP == 54) OPK("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf");
+            if (OP == 55) OPK("v_bcnt_u32_b32 %0, %1, %0");
+            if (OP == 56) OPK("v_sad_u8 %0, %0, %1, %2");
+            if (OP == 57) OPK("v_pk_mad_u16 %0, %0, %1, %2");
+            if (OP == 58) OPK("v_pk_lshrrev_b16 %0, 1, %0 op_sel_hi:[0,1]");
+            if (OP == 59) OPK("v_cvt_f32_i32 %0, %0");
+            if (OP == 60) OPK("v_min3_i32 %0, %0, %1, %2");
+            if (OP == 61) OPK("v_add_co_u32 %0, vcc, %0, %1");
+            if (OP == 62) OPK("v_sub_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2");
+            if (OP == 63) OPK("v_mad_i32_i24 %0, %0, %1, %2");
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -70,7 +102,8 @@ static const char *NAMES[] = {"v_add_u32", "v_max_i32", "v_max3_i32", "v_cmp_gt_
     "v_add_u32_sdwa(sext byte)", "v_pk_add_i16", "v_pk_max_i16", "v_max_f32", "v_add_f32", "v_max3_f32", "v_cmp_gt_f32",
     "v_lshl_add_u32", "v_and_b32", "v_max_u32", "v_sub_u32", "v_add3_u32", "v_max_i16", "v_bfe_i32", "v_mov_b32",
     "v_alignbit_b32", "v_fma_f32", "v_pk_max_f16", "v_subb_co_u32", "v_med3_i32", "v_pk_sub_i16", "v_perm_b32", "v_max_f16",
-    "v_cmp_gt_i32+v_addc_co_u32 (pair)", "v_xor_b32", "v_min_i32"};
+    "v_cmp_gt_i32+v_addc_co_u32 (pair)", "v_xor_b32", "v_min_i32",
+    "v_dot4_i32_i8", "v_dot4c_i32_i8", "v_sub_co_u32", "v_add_u16", "v_sub_u16", "v_max_u16", "v_min_i16", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_or_b32", "v_lshl_or_b32", "v_and_or_b32", "v_bfi_b32", "v_sub_u32 clamp", "v_mad_u32_u24", "v_mul_u32_u24", "v_mad_u16", "v_alignbyte_b32", "v_add_u16_sdwa(sext byte)", "v_max_i16_sdwa(word1)", "v_add_u32 dpp wave_shr", "v_mov_b32 dpp wave_shr", "v_bcnt_u32_b32", "v_sad_u8", "v_pk_mad_u16", "v_pk_lshrrev_b16", "v_cvt_f32_i32", "v_min3_i32", "v_add_co_u32", "v_sub_u32 sdwa sext byte", "v_mad_i32_i24"};
 
 template <int OP>
 void run(int *d_out, unsigned long long *d_clk, int cus, int waves_per_simd)
@@ -106,7 +139,7 @@ template <int OP>
 void run_all(int *d_out, unsigned long long *d_clk, int cus)
 {
     run<OP>(d_out, d_clk, cus, 8);
-    if constexpr (OP + 1 < 32) run_all<OP + 1>(d_out, d_clk, cus);
+    if constexpr (OP + 1 < 64) run_all<OP + 1>(d_out, d_clk, cus);
 }
 
 int main()
