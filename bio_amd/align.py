@@ -178,7 +178,7 @@ def AlignLocal(s1: bytes, s2: bytes, a, indelPenalty: int):
 
 def AlignPairLong(mode: str, s1: bytes, s2: bytes, a, indelPenalty: int):
     """AlignPair for ONE long pair: same result, computed by the intra-sequence wavefront
-    kernels (bioalign_long).  global / fitting / overlap, linear gap, <= 64 distinct column symbols."""
+    kernels (bioalign_long).  All four modes, linear gap, <= 64 distinct column symbols."""
     if mode not in _native.MODES:
         return -1, None, None
     sc, t1, t2 = _run_batch(mode, [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty, long=True)

@@ -1195,8 +1195,9 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     const uint64_t wps = (m + 63 + cpd - 1) / cpd;
 
     HIP_TRY(ctx, hipSetDevice(ctx->devices[0]));
-    DevBuf d_s1, d_s2, d_prof, d_c1, d_c2, d_tab, d_bnd, d_res, d_misc, d_t1, d_t2, d_ops;
+    DevBuf d_s1, d_s2, d_prof, d_c1, d_c2, d_tab, d_bnd, d_res, d_misc, d_t1, d_t2, d_ops, d_lmax;
     int rc;
+    if (in->mode == BIOALIGN_LOCAL && (rc = d_lmax.alloc(ctx, strips * 64 * 4))) return rc;
     if ((rc = d_s1.alloc(ctx, n + 16)) || (rc = d_s2.alloc(ctx, m + 16)) || (rc = d_prof.alloc(ctx, rowprof.size() * 4)) ||
         (rc = d_c1.alloc(ctx, 256)) || (rc = d_c2.alloc(ctx, 256)) || (rc = d_tab.alloc(ctx, (size_t)in->na * in->nb * 4)) ||
         (rc = d_bnd.alloc(ctx, nsuper * ((m + 15) / 16 * 16) * 8 + 256)) ||
@@ -1236,6 +1237,7 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     P.resid = d_res.as<uint32_t>();
     // misc: [0] status, [8] score, [16] t_off, [24] t_len, [32..43] walk
     P.status = d_misc.as<uint32_t>();
+    P.lane_max = d_lmax.as<int32_t>();
     P.table = d_tab.as<int32_t>();
     P.nb = in->nb;
     P.gap_symbol = in->gap_symbol;
@@ -1325,12 +1327,13 @@ int long_geometry(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t n, uin
                   std::vector<uint32_t> *rowprof)
 {
     const int g = in->gap_open;
+    const int bias = in->mode == BIOALIGN_LOCAL ? g : 2 * g;  // what the profile adds to w (kernels_long.hip)
     if (in->nb > 64)
         return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode keeps a strip profile of 256 bytes per column symbol and wavefront "
                                                 "in LDS: at most 64 distinct column symbols (got %d)", in->nb);
     int wmax = 0;
     for (int i = 0; i < in->na * in->nb; ++i) {
-        const int64_t v = (int64_t)in->score_table[i] + 2 * g;
+        const int64_t v = (int64_t)in->score_table[i] + bias;
         if (v < -127 || v > 127)
             return ctx->fail(BIOALIGN_EUNSUPPORTED, "score %d with gap %d does not fit the int8 row profile",
                              in->score_table[i], g);
@@ -1348,7 +1351,7 @@ int long_geometry(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t n, uin
     rowprof->assign((bytes + 3) / 4, 0x80808080u);
     int8_t *tab = reinterpret_cast<int8_t *>(rowprof->data());
     for (int a = 0; a < in->na; ++a)
-        for (int b = 0; b < in->nb; ++b) tab[(size_t)a * in->nb + b] = (int8_t)(in->score_table[a * in->nb + b] + 2 * g);
+        for (int b = 0; b < in->nb; ++b) tab[(size_t)a * in->nb + b] = (int8_t)(in->score_table[a * in->nb + b] + bias);
     return 0;
 }
 
@@ -1714,8 +1717,6 @@ extern "C" int bioalign_long(bioalign_ctx *ctx, const bioalign_batch_t *in, bioa
     if (kernel_ms) *kernel_ms = 0.f;
     if (in->gap_open != in->gap_extend)
         return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode covers linear gaps only (affine: use bioalign_batch)");
-    if (in->mode == BIOALIGN_LOCAL)
-        return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode covers global, fitting and overlap (local: use bioalign_batch)");
     if (in->gap_open < 0) return ctx->fail(BIOALIGN_EUNSUPPORTED, "negative gap penalty %d", in->gap_open);
     for (uint64_t p = 0; p < N; ++p) {
         const uint64_t n = in->s1_off[p + 1] - in->s1_off[p], m = in->s2_off[p + 1] - in->s2_off[p];
@@ -1731,7 +1732,8 @@ extern "C" int bioalign_long(bioalign_ctx *ctx, const bioalign_batch_t *in, bioa
         } else {
             // column stripes over the context's devices when the residue words (K bits per cell, K <= 8) may not
             // fit one device, or when BIOALIGN_LONG_STRIPES asks for them
-            int stripes = (int)env_u64("BIOALIGN_LONG_STRIPES", 0);
+            // (local mode runs unstriped: its end cell is a maximum over the whole matrix)
+            int stripes = in->mode == BIOALIGN_LOCAL ? 1 : (int)env_u64("BIOALIGN_LONG_STRIPES", 0);
             if (stripes == 0 && ctx->devices.size() > 1) {
                 size_t free_b = 0, total_b = 0;
                 HIP_TRY(ctx, hipSetDevice(ctx->devices[0]));
@@ -1764,7 +1766,7 @@ extern "C" bioalign_stripe *bioalign_stripe_create(bioalign_ctx *ctx, int device
         return nullptr;
     }
     if (in->mode != BIOALIGN_GLOBAL && in->mode != BIOALIGN_FITTING && in->mode != BIOALIGN_OVERLAP) {
-        ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode covers global, fitting and overlap");
+        ctx->fail(BIOALIGN_EUNSUPPORTED, "column stripes cover global, fitting and overlap (local mode runs unstriped)");
         return nullptr;
     }
     if (in->gap_open != in->gap_extend || in->gap_open < 0) {

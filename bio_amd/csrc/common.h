@@ -118,6 +118,7 @@ struct BaLongParams {
     uint32_t epoch;                // tag of this launch's granules: 1 .. 0x7ffffffe (top bit: poisoned)
     uint32_t *resid;               // [strips][words_per_strip][64 lanes]
     uint32_t *status;              // != 0: a wait ran out (should never happen)
+    int32_t *lane_max;             // local mode: [strips][64] the largest score each lane saw in its T rows
     // traceback
     const int32_t *table;          // na * nb scores as the caller gave them
     int nb;

@@ -1,5 +1,5 @@
 // kernels_long.hip -- long mode: ONE pair aligned by many wavefronts (intra-sequence,
-// anti-diagonal wavefront), linear gap, global / fitting / overlap.
+// anti-diagonal wavefront), linear gap, global / local / fitting / overlap.
 //
 // Same recurrences, tie priorities and working score space as kernels.hip
 // (Hs = H + g*(i+j); cell = max3(up, left, diag + w + 2g); K-bit residues of every cell as
@@ -83,8 +83,11 @@ struct BaLongWaveLds {
 // One step of one lane: T cells of one column.  `pw` holds the substitution scores of the lane's T rows against this
 // column's symbol, one signed byte per row (from the lane's strip profile in LDS): the byte is an SDWA operand of the add.
 // CHECK: the lane may be outside its column range (start-up and drain of the skew) and must then keep its state.
-template <int T, int K, bool CHECK>
-__device__ __forceinline__ void ba_long_step(int (&h)[T], uint32_t &acc, int top, int diag0, uint32_t pw, bool active)
+// LOCAL: true scores (no bias), H = max(0, max(up, left) - g, diag + w) with w + g in the profile: one max3 and one
+// saturating unsigned subtract, as kernels.hip does it; `lmax` collects the largest score the lane has seen.
+template <int T, int K, bool CHECK, bool LOCAL>
+__device__ __forceinline__ void ba_long_step(int (&h)[T], uint32_t &acc, int top, int diag0, uint32_t pw, bool active, int g,
+                                             int &lmax)
 {
     int up = top, diag = diag0;
 #pragma unroll
@@ -92,11 +95,17 @@ __device__ __forceinline__ void ba_long_step(int (&h)[T], uint32_t &acc, int top
         const int left = h[r];
         const int d = diag + ba_sbyte(pw, r);
         int hn = ba_max3(up, left, d);
+        if (LOCAL) hn = (int)__builtin_elementwise_sub_sat((uint32_t)hn, (uint32_t)g);  // (max3 >= up >= 0)
         if (CHECK) hn = active ? hn : left;
         acc = __builtin_amdgcn_alignbit((uint32_t)hn, acc, K);
         diag = left;
         h[r] = hn;
         up = hn;
+    }
+    if (LOCAL) {
+        if (T == 1) lmax = max(lmax, h[0]);
+#pragma unroll
+        for (int r = 0; r + 1 < T; r += 2) lmax = ba_max3(lmax, h[r], h[r + 1]);
     }
 }
 
@@ -337,6 +346,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     // before the first step that is column 0 of the row above: my upper neighbour's initial bottom
     int topprev = ba_wave_shr1(left_top, bottom);
     uint32_t acc = 0;
+    int lmax = 0;  // local: the largest score of my rows so far
 
     const uint32_t *oh_me = L.ohw + 64 - lane;  // my window slot for step 0 of a block
 
@@ -394,7 +404,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int top = ba_wave_shr1(tin[k], bottom);
-                    ba_long_step<T, K, false>(h, acc, top, topprev, pw[k], true);
+                    ba_long_step<T, K, false, MODE == BA_LOCAL>(h, acc, top, topprev, pw[k], true, g, lmax);
                     topprev = top;
                     bottom = h[T - 1];
                     ba_lds_store((j * 16 + k == 63) ? wp63 : wp + j * 16 + k, bottom);
@@ -407,7 +417,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
                     if (t < total_steps) {
                         const int top = ba_wave_shr1(tin[k], bottom);
                         const bool active = (t >= lane) && (t - lane < m);
-                        ba_long_step<T, K, true>(h, acc, top, topprev, pw[k], active);
+                        ba_long_step<T, K, true, MODE == BA_LOCAL>(h, acc, top, topprev, pw[k], active, g, lmax);
                         topprev = top;
                         bottom = h[T - 1];
                         ba_lds_store((j * 16 + k == 63) ? wp63 : wp + j * 16 + k, bottom);
@@ -473,6 +483,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     } else {
         publish(prog_out, (uint32_t)m);
     }
+    if (MODE == BA_LOCAL) P.lane_max[(size_t)s * 64 + lane] = lmax;
     // column stripes: my last column is the next stripe's column 0
     if (P.right_col) {
 #pragma unroll
@@ -516,6 +527,128 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
 // ----------------------------------------------------------------------------
 enum { BA_MV_UP = 0, BA_MV_LEFT = 1, BA_MV_DIAG = 2 };
 
+// Local mode: the end cell is the first maximum in row-major order (align.go:216-221).  The DP left the largest
+// score of every lane's T rows (lane_max, in row order); this kernel finds the maximum M and the first lane group that
+// holds it, then rebuilds the exact scores of that group's rows, one row after the other, from the residues --
+// H(i, 0) = 0 and a horizontal step is ((rho(j) - rho(j-1) + g) mod 2^K) - g -- as a block-wide prefix sum over the
+// columns, until a row shows M: its first such column is the end cell.  One block; leaves (i, j, M) in P.walk.
+template <int T, int K>
+__global__ void __launch_bounds__(1024) ba_long_local_find_kernel(BaLongParams P)
+{
+    using G = BaLongGeom<T, K>;
+    constexpr int RS = G::RS, CPD = G::CPD;
+    constexpr uint32_t MASK = (1u << K) - 1u;
+    __shared__ int red_v[16];
+    __shared__ uint32_t red_k[16];
+    __shared__ int wsum[16];
+    __shared__ int found_s[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = (int)P.n, m = (int)P.m, g = P.gap;
+    const int strips = (int)P.strips;
+    const int wps = (int)P.words_per_strip;
+    // the maximum and the first lane group (strip * 64 + lane: row order) that holds it
+    int best = 0;
+    uint32_t bk = 0xffffffffu;
+    for (uint32_t k = (uint32_t)tid; k < (uint32_t)strips * 64u; k += 1024u) {
+        const int v = P.lane_max[k];
+        if (v > best || (v == best && k < bk)) {
+            best = v;
+            bk = k;
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int ov = __shfl_xor(best, d);
+        const uint32_t ok = (uint32_t)__shfl_xor((int)bk, d);
+        if (ov > best || (ov == best && ok < bk)) {
+            best = ov;
+            bk = ok;
+        }
+    }
+    if (lane == 0) {
+        red_v[wave] = best;
+        red_k[wave] = bk;
+    }
+    __syncthreads();
+    best = red_v[0];
+    bk = red_k[0];
+    for (int q = 1; q < 16; ++q)
+        if (red_v[q] > best || (red_v[q] == best && red_k[q] < bk)) {
+            best = red_v[q];
+            bk = red_k[q];
+        }
+    const int M = best;
+    int fi = 0, fj = 0;
+    if (M > 0) {
+        const int s = (int)(bk >> 6), l = (int)(bk & 63u);
+        const int i0 = n - (strips - s) * RS;
+        const int chunk = (m + 1023) / 1024;
+        const int c_lo = tid * chunk + 1, c_hi = min(c_lo + chunk - 1, m);  // my columns (1-based); empty if c_lo > m
+        for (int r = 0; r < T && fi == 0; ++r) {
+            const int i = i0 + l * T + r + 1;
+            if (i < 1) continue;  // (uniform) a row above the matrix
+            const uint32_t *row = P.resid + (size_t)s * wps * 64 + l;
+            auto rho = [&](int j) -> uint32_t {  // residue of H(i, j), j >= 0
+                if (j == 0) return 0u;
+                const int t = (j - 1) + l;
+                return (row[(size_t)(t / CPD) * 64] >> (uint32_t)(((t % CPD) * T + r) * K)) & MASK;
+            };
+            int sum = 0;
+            if (c_lo <= m) {
+                uint32_t prev = rho(c_lo - 1);
+                for (int j = c_lo; j <= c_hi; ++j) {
+                    const uint32_t cur = rho(j);
+                    sum += (int)((cur - prev + (uint32_t)g) & MASK) - g;
+                    prev = cur;
+                }
+            }
+            // exclusive prefix of the chunk sums over the block
+            int incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int a = __shfl_up(incl, d);
+                if (lane >= d) incl += a;
+            }
+            __syncthreads();  // (wsum / found_s of the previous row have been read)
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            int base = incl - sum;
+            for (int q = 0; q < wave; ++q) base += wsum[q];
+            int found = 0x7fffffff;
+            if (c_lo <= m) {
+                int v = base;
+                uint32_t prev = rho(c_lo - 1);
+                for (int j = c_lo; j <= c_hi; ++j) {
+                    const uint32_t cur = rho(j);
+                    v += (int)((cur - prev + (uint32_t)g) & MASK) - g;
+                    prev = cur;
+                    if (v == M && found == 0x7fffffff) found = j;
+                }
+            }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) found = min(found, __shfl_xor(found, d));
+            if (lane == 0) found_s[wave] = found;
+            __syncthreads();
+            found = found_s[0];
+            for (int q = 1; q < 16; ++q) found = min(found, found_s[q]);
+            if (found != 0x7fffffff) {
+                fi = i;
+                fj = found;
+            }
+        }
+    }
+    if (tid == 0) {
+        *P.score = (int64_t)M;
+        P.walk[0] = (uint32_t)fi;
+        P.walk[1] = (uint32_t)fj;
+        P.walk[2] = 0;
+        P.walk[3] = (uint32_t)M;
+        P.walk[4] = (uint32_t)fi;
+        P.walk[5] = (uint32_t)fj;
+        if (M > 0 && fi == 0) atomicAdd(P.status, 1u);  // (cannot happen: some row of the group holds M)
+    }
+}
+
 template <int MODE, int T, int K>
 __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
 {
@@ -532,8 +665,10 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
 
     const int b_top = (MODE == BA_FITTING) ? g : 0;
     const int b_left = (MODE == BA_OVERLAP) ? g : 0;
-    constexpr bool top_free = (MODE == BA_FITTING);
-    constexpr bool left_free = (MODE == BA_OVERLAP);
+    constexpr bool top_free = (MODE == BA_FITTING || MODE == BA_LOCAL);
+    constexpr bool left_free = (MODE == BA_OVERLAP || MODE == BA_LOCAL);
+    // local: true scores; a step between neighbours is never below -g (kernels.hip); other modes: biased space, never below 0
+    const uint32_t off = (MODE == BA_LOCAL) ? (uint32_t)g : 0u;
     // the last strip is the last wave of the last workgroup; its bottom row lies in HBM as {score, tag} granules
     const int32_t *bottom_row = P.bnd + (size_t)(P.nsuper - 1) * P.bnd_stride * 2;
     // column stripes: columns are the stripe's own (1..m), column 0 belongs to the stripe on the left
@@ -543,7 +678,12 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
 
     // end cell (align.go:123-124; align_pair.go:169-182): n >= 1 and m >= 1 here
     int i = n, j = m, cur = 0, bv = 0;
-    if (P.start_j >= 0) {
+    if (MODE == BA_LOCAL) {
+        // ba_long_local_find_kernel has found the end cell and written the score
+        i = (int)P.walk[0];
+        j = (int)P.walk[1];
+        cur = bv = (int)P.walk[3];
+    } else if (P.start_j >= 0) {
         // the walk comes in from the stripe on the right (or the host has chosen the end cell)
         i = P.start_i;
         j = P.start_j;
@@ -584,7 +724,7 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
     cur = __builtin_amdgcn_readfirstlane(cur);
     bv = __builtin_amdgcn_readfirstlane(bv);
     if (lane == 0) {
-        if (P.start_j < 0) *P.score = (int64_t)cur - (int64_t)g * (i + col0 + j);
+        if (P.start_j < 0 && MODE != BA_LOCAL) *P.score = (int64_t)cur - (int64_t)g * (i + col0 + j);
         P.walk[0] = (uint32_t)i;  // where the walk starts
         P.walk[1] = (uint32_t)j;
         P.walk[2] = 0;
@@ -691,11 +831,12 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
     while (i > 0 && j > 0) {
         const int ii = i - lane, jj = j - lane;
         bool ok = ii >= 1 && jj >= 1;
-        uint32_t rcq = 0, ruq = 0, rlq = 0;
+        uint32_t rcq = 0, ruq = 0, rlq = 0, rdq = 0;
         if (ok) {
             rcq = peek(ii, jj, ok);
             ruq = peek(ii - 1, jj, ok);
             rlq = peek(ii, jj - 1, ok);
+            if (MODE == BA_LOCAL) rdq = peek(ii - 1, jj - 1, ok);
         }
         const uint64_t okmask = __ballot(ok);
         if (!(okmask & 1ull)) {
@@ -703,14 +844,54 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
             (void)residue(i, j);
             (void)residue(i - 1, j);
             (void)residue(i, j - 1);
+            if (MODE == BA_LOCAL) (void)residue(i - 1, j - 1);
             continue;
         }
-        const bool above_up = ((rcq - ruq) & MASK) != 0;    // cur > up
-        const bool above_left = ((rcq - rlq) & MASK) != 0;  // cur > left
+        // local: cur = max(0, up - g, left - g, diag + w) > 0, up > left > diagonal (align.go:186-202): "cur > up - g" is
+        // "the residues differ by something other than -g"; the other modes: off = 0
+        const bool above_up = ((rcq - ruq + off) & MASK) != 0;    // cur > up (local: cur > up - g)
+        const bool above_left = ((rcq - rlq + off) & MASK) != 0;  // cur > left (local: cur > left - g)
         const bool is_diag = ok && above_up && above_left;
         const uint32_t mvq = (!above_left && above_up) ? BA_MV_LEFT : BA_MV_UP;
         const uint64_t dmask = __ballot(is_diag);
-        const uint32_t run = dmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~dmask);
+        uint32_t run = dmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~dmask);
+        if (MODE == BA_LOCAL) {
+            // exact scores along the diagonal: H(ii, jj) - H(ii-1, jj-1) = (cur - up) + (up - diag), both steps known
+            // from the residues; the walk ends at the first cell that scores 0 (align.go:224-226)
+            const int d_up = (int)((rcq - ruq + off) & MASK) - g, d_left = (int)((rcq - rlq + off) & MASK) - g;
+            const int dq = d_up + (int)((ruq - rdq + off) & MASK) - g;
+            int incl = ok ? dq : 0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int a = __shfl_up(incl, d);
+                if (lane >= d) incl += a;
+            }
+            const int hq = cur - (incl - (ok ? dq : 0));  // exact H of my cell, valid while every lane below me is a diagonal move
+            const uint64_t zmask = __ballot(ok && hq == 0);
+            const uint32_t stop = zmask ? (uint32_t)__builtin_ctzll(zmask) : 64u;
+            if (zmask && stop <= run) {
+                emit_run(BA_MV_DIAG, stop);
+                i -= (int)stop;
+                j -= (int)stop;
+                break;
+            }
+            emit_run(BA_MV_DIAG, run);
+            i -= (int)run;
+            j -= (int)run;
+            if (run > 0) cur -= __builtin_amdgcn_readlane(incl, (int)run - 1);
+            if (run < 64 && ((okmask >> run) & 1ull)) {
+                const uint32_t mv = (uint32_t)__builtin_amdgcn_readlane((int)mvq, (int)run);
+                emit(mv);
+                if (mv == BA_MV_LEFT) {
+                    --j;
+                    cur -= __builtin_amdgcn_readlane(d_left, (int)run);
+                } else {
+                    --i;
+                    cur -= __builtin_amdgcn_readlane(d_up, (int)run);
+                }
+            }
+            continue;
+        }
         emit_run(BA_MV_DIAG, run);
         i -= (int)run;
         j -= (int)run;
@@ -819,10 +1000,14 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
     hipError_t e = hipSuccess;
     if ((phases & BA_LONG_PHASE_DP) && P.multi) {
         // several stripes in one launch: wg_count = the workgroups of all of them (P.order)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
-        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K, true>), dim3(P.wg_count), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if constexpr (MODE == BA_LOCAL) {
+            return hipErrorInvalidValue;  // (local mode runs unstriped)
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
+            hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K, true>), dim3(P.wg_count), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
     } else if (phases & BA_LONG_PHASE_DP) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
@@ -831,6 +1016,10 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (phases & BA_LONG_PHASE_WALK) {
+        if constexpr (MODE == BA_LOCAL) {
+            hipLaunchKernelGGL((ba_long_local_find_kernel<T, K>), dim3(1), dim3(1024), 0, st, P);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
         hipLaunchKernelGGL((ba_long_walk_kernel<MODE, T, K>), dim3(1), dim3(64), 0, st, P);
         if ((e = hipGetLastError()) != hipSuccess || P.score_only || P.scan_only) return e;
         hipLaunchKernelGGL(ba_long_expand_kernel, dim3(1), dim3(1024), 0, st, P);
@@ -880,6 +1069,9 @@ extern "C" hipError_t ba_launch_long(const BaLongParams &P, int mode, int T, int
     }
     switch (mode) {
     case BA_GLOBAL: return launch_long_mode<BA_GLOBAL>(P, T, K, phases, st);
+    case BA_LOCAL:
+        if (!P.lane_max || P.left_col || P.right_col || P.col0) return hipErrorInvalidValue;  // (unstriped only)
+        return launch_long_mode<BA_LOCAL>(P, T, K, phases, st);
     case BA_FITTING: return launch_long_mode<BA_FITTING>(P, T, K, phases, st);
     case BA_OVERLAP: return launch_long_mode<BA_OVERLAP>(P, T, K, phases, st);
     }

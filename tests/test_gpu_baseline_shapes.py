@@ -103,7 +103,7 @@ def test_config4_long_pair_20k_against_the_two_column_pass():
     assert int(col[-1]) == score
     # fitting / overlap at the same size: the bottom row's leftmost best cell is a property of the last column pass
     # of the transposed problem only for global, so these two are checked through their trace properties
-    for mode in ("fitting", "overlap"):
+    for mode in ("fitting", "overlap", "local"):
         sc, t1, t2, toff, tlen = eng.long(_native.PackedBatch(s1, o1, s2, o2, mode, table, c1, c2, 1, 1))
         a, l = int(toff[0]), int(tlen[0])
         x, y = t1[a:a + l], t2[a:a + l]
@@ -111,8 +111,10 @@ def test_config4_long_pair_20k_against_the_two_column_pass():
         xs, ys = x[x != gap].tobytes(), y[y != gap].tobytes()
         if mode == "fitting":
             assert xs == s1.tobytes() and ys in s2.tobytes()
-        else:
+        elif mode == "overlap":
             assert s1.tobytes().endswith(xs) and s2.tobytes().startswith(ys)
+        else:
+            assert xs in s1.tobytes() and ys in s2.tobytes()
         assert int(np.where((x == gap) | (y == gap), -1, np.where(x == y, 1, -1)).sum()) == int(sc[0])
         assert int(sc[0]) >= score  # a free border can only help
 

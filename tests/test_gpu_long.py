@@ -1,5 +1,5 @@
 """GPU parity, long mode: one pair aligned by the intra-sequence wavefront
-kernels (bioalign_long) against the oracle, bit for bit on score and both traces.  Sizes are chosen
+kernels (bioalign_long), four modes, against the oracle, bit for bit on score and both traces.  Sizes are chosen
 around the kernel's seams: one / several strips of 64*T rows, column counts around the 64-column
 hand-over blocks, the three residue widths."""
 import random
@@ -22,7 +22,10 @@ def _pair(n, m, seed, div=True):
     return s1.tobytes(), s2.tobytes()
 
 
-@pytest.mark.parametrize("mode", ["global", "fitting", "overlap"])
+MODES4 = ["global", "local", "fitting", "overlap"]
+
+
+@pytest.mark.parametrize("mode", MODES4)
 def test_long_small_shapes(mode):
     a, oa = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
     shapes = [(1, 1), (5, 7), (7, 5), (63, 64), (64, 63), (65, 65), (100, 127), (128, 128), (130, 129),
@@ -38,7 +41,7 @@ def test_long_residue_widths(scoring):
     a, oa = bio_amd.MatchAligner(ma, mi), O.MatchAligner(ma, mi)
     for k, (n, m) in enumerate([(300, 310), (1030, 520), (260, 777)]):
         x, y = _pair(n, m, 300 + k)
-        for mode in ("global", "fitting", "overlap"):
+        for mode in MODES4:
             assert bio_amd.AlignPairLong(mode, x, y, a, g) == O.AlignPair(mode, x, y, oa, g), (scoring, mode, n, m)
 
 
@@ -48,8 +51,33 @@ def test_long_low_complexity_ties():
     for _ in range(6):
         x = bytes(rng.choice(b"AAAC") for _ in range(rng.randrange(400, 1300)))
         y = bytes(rng.choice(b"AAAC") for _ in range(rng.randrange(400, 1300)))
-        for mode in ("global", "fitting", "overlap"):
+        for mode in MODES4:
             assert bio_amd.AlignPairLong(mode, x, y, a, 1) == O.AlignPair(mode, x, y, oa, 1)
+
+
+def test_long_local_end_cells_and_empty_alignments():
+    # align.go:152-249 on the long kernels: first maximum in row-major order, walk back to the first cell that scores 0
+    a, oa = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
+    rng = random.Random(31)
+    core = bytes(rng.choice(b"ACGT") for _ in range(200))
+    junk = lambda k, al=b"ACGT": bytes(rng.choice(al) for _ in range(k))
+    cases = [
+        (b"A" * 300, b"C" * 500),                                  # nothing matches: score 0, empty traces
+        (core, core),                                              # the whole diagonal
+        (junk(400) + core + junk(300), junk(150) + core + junk(700)),  # a core inside junk
+        (core + junk(500) + core, junk(300) + core + junk(100)),   # the maximum occurs twice: the first row wins
+        (junk(300) + core, core + junk(300) + core),               # ... and twice in one row: the first column wins
+        (b"ACGT" * 200, b"ACGT" * 150),                            # periodic: many equal maxima
+        (junk(1500, b"AC"), junk(1300, b"AC")),
+    ]
+    for x, y in cases:
+        assert bio_amd.AlignPairLong("local", x, y, a, 1) == O.AlignPair("local", x, y, oa, 1), (len(x), len(y))
+    # the maximum in the last row / last column / first row, and a start at the matrix's corner
+    for x, y in [(junk(700) + core, junk(90) + core), (core + junk(5), core), (b"G", junk(300) + b"G"), (core, core + junk(900))]:
+        assert bio_amd.AlignPairLong("local", x, y, a, 1) == O.AlignPair("local", x, y, oa, 1), (len(x), len(y))
+    # AlignLocal itself through the long kernels' size threshold is not routed: AlignPairLong is the entry point
+    sc = bio_amd.AlignPairBatch("local", [cases[2][0]], [cases[2][1]], a, 1)
+    assert (sc[0][0], sc[1][0], sc[2][0]) == bio_amd.AlignPairLong("local", cases[2][0], cases[2][1], a, 1)
 
 
 def test_long_several_strips_and_align_global_ls():
@@ -65,12 +93,17 @@ def test_long_several_strips_and_align_global_ls():
 
 
 def test_long_unsupported_fails_loudly():
-    with pytest.raises(bio_amd._native.BioAlignError) as e:
-        bio_amd.AlignPairLong("local", b"ACGT" * 10, b"ACG" * 10, bio_amd.MatchAligner(1, -1), 1)
-    assert e.value.code == bio_amd._native.EUNSUPPORTED
+    # affine gaps are the batch kernels' (bioalign_batch); long mode says so instead of computing something else
+    from bio_amd import _native, pack_sequences, score_table
+    d1, o1 = pack_sequences([b"ACGT" * 10]); d2, o2 = pack_sequences([b"ACG" * 10])
+    tbl, c1, c2 = score_table(bio_amd.MatchAligner(1, -1), np.unique(d1).tolist(), np.unique(d2).tolist())
+    pb = _native.PackedBatch(d1, o1, d2, o2, "global", tbl, c1, c2, gap_open=5, gap_extend=1)
+    with pytest.raises(_native.BioAlignError) as e:
+        bio_amd.align.engine().batch(pb, long=True)
+    assert e.value.code == _native.EUNSUPPORTED
 
 
-@pytest.mark.parametrize("mode", ["global", "fitting", "overlap"])
+@pytest.mark.parametrize("mode", MODES4)
 def test_long_protein_alphabets(mode):
     # any alphabet up to 64 column symbols: the strip profile of a lane lies in LDS (20 symbols, 8 residue bits here)
     s1, o1, s2, o2 = synth.protein_pairs(1, 3100, 3300, config=3, first=7)
