@@ -6,6 +6,7 @@ usable, importing works but every alignment call raises.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import os
 import sys
 
@@ -267,9 +268,12 @@ class Engine:
         if not h:
             raise BioAlignError(ENODEVICE, L.bioalign_last_error(None).decode())
         self._h = C.c_void_p(h)
+        self._children = weakref.WeakSet()  # plans, stripes, fasta objects: they go before the context (bioalign.h)
 
     def close(self):
         if getattr(self, "_h", None):
+            for child in list(getattr(self, "_children", ())):
+                child.close()
             lib().bioalign_destroy(self._h)
             self._h = None
 
@@ -383,6 +387,7 @@ class Plan:
         if not h:
             raise BioAlignError(EINVAL, lib().bioalign_last_error(engine._h).decode())
         self._h = C.c_void_p(h)
+        engine._children.add(self)
         self.n_pairs = pb.n_pairs
 
     def close(self):
@@ -440,6 +445,7 @@ class Stripe:
         if not h:
             engine._raise(EINVAL)
         self._h = C.c_void_p(h)
+        engine._children.add(self)
         self.rows = int(lib().bioalign_stripe_rows(self._h))
         self.width = self.col_end - self.col_begin
 
@@ -519,6 +525,7 @@ class Fasta:
         if not h:
             engine._raise(EINVAL)
         self._h = C.c_void_p(h)
+        engine._children.add(self)
         L = lib()
         self.too_long_at = int(L.bioalign_fasta_too_long_at(self._h))
         self.count = int(L.bioalign_fasta_count(self._h))

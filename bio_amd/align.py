@@ -123,6 +123,25 @@ def _run_batch(mode, s1s, s2s, a, gap_open, gap_extend, score_only=False, long=F
     return [int(x) for x in scores], out1, out2
 
 
+def _trace_quirk(t1, t2):
+    """AlignPair's trace() (align_pair.go:197-216) appends a symbol only if it is not 0 -- a NUL byte of a sequence (or
+    a GapSymbol of 0) is silently dropped from its own trace -- and then reverses both traces in one loop that runs
+    over len(t1)/2 and indexes both with len(t1)-1: when the two traces have lost different numbers of bytes, t2 comes
+    out partly reversed, or the loop indexes past its end and Go panics.  Reproduced here on the host, O(trace), only
+    for traces that hold a 0 byte; (t1, t2) are the aligned traces the kernels return, front to back."""
+    if (t1 is None or 0 not in t1) and (t2 is None or 0 not in t2):
+        return t1, t2
+    r1 = bytearray(b for b in reversed(t1 or b"") if b != 0)  # as appended while walking back
+    r2 = bytearray(b for b in reversed(t2 or b"") if b != 0)
+    last = len(r1) - 1
+    for i in range(len(r1) // 2):
+        r1[i], r1[last - i] = r1[last - i], r1[i]
+        if last - i >= len(r2):
+            raise IndexError(f"index out of range [{last - i}] with length {len(r2)}")  # the reference panics here
+        r2[i], r2[last - i] = r2[last - i], r2[i]
+    return (bytes(r1) or None), (bytes(r2) or None)
+
+
 def AlignPairBatch(mode: str, s1s, s2s, a, indelPenalty: int, score_only: bool = False):
     """Batch form of AlignPair: (scores, t1s, t2s), one entry per pair."""
     if len(s1s) != len(s2s):
@@ -132,7 +151,11 @@ def AlignPairBatch(mode: str, s1s, s2s, a, indelPenalty: int, score_only: bool =
         return [-1] * n, [None] * n, [None] * n  # align_pair.go:14-15
     if not s1s:
         return [], [], []
-    return _run_batch(mode, list(s1s), list(s2s), a, indelPenalty, indelPenalty, score_only)
+    sc, t1s, t2s = _run_batch(mode, list(s1s), list(s2s), a, indelPenalty, indelPenalty, score_only)
+    if not score_only:
+        for p in range(len(sc)):
+            t1s[p], t2s[p] = _trace_quirk(t1s[p], t2s[p])
+    return sc, t1s, t2s
 
 
 def AlignAffineBatch(mode: str, s1s, s2s, a, gapOpenPenalty: int, gapExtendPenalty: int,
@@ -159,7 +182,7 @@ def AlignPair(mode: str, s1: bytes, s2: bytes, a, indelPenalty: int):
     if mode not in _native.MODES:
         return -1, None, None
     sc, t1, t2 = _run_batch(mode, [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty)
-    return sc[0], t1[0], t2[0]
+    return (sc[0],) + _trace_quirk(t1[0], t2[0])
 
 
 def AlignGlobal(s1: bytes, s2: bytes, a, indelPenalty: int):
@@ -168,12 +191,14 @@ def AlignGlobal(s1: bytes, s2: bytes, a, indelPenalty: int):
         # The reference's own traceback indexes s2[-1] here (stride 1 makes the two gap
         # deltas equal, align.go:128-130) and panics; keep the error behaviour.
         raise IndexError("index out of range [-1]")
-    return AlignPair("global", s1, s2, a, indelPenalty)
+    sc, t1, t2 = _run_batch("global", [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty)
+    return sc[0], t1[0], t2[0]  # (align.go:126-143 appends every byte: no NUL quirk here)
 
 
 def AlignLocal(s1: bytes, s2: bytes, a, indelPenalty: int):
     """align.go:152-249."""
-    return AlignPair("local", s1, s2, a, indelPenalty)
+    sc, t1, t2 = _run_batch("local", [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty)
+    return sc[0], t1[0], t2[0]
 
 
 def AlignPairLong(mode: str, s1: bytes, s2: bytes, a, indelPenalty: int):
@@ -182,7 +207,7 @@ def AlignPairLong(mode: str, s1: bytes, s2: bytes, a, indelPenalty: int):
     if mode not in _native.MODES:
         return -1, None, None
     sc, t1, t2 = _run_batch(mode, [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty, long=True)
-    return sc[0], t1[0], t2[0]
+    return (sc[0],) + _trace_quirk(t1[0], t2[0])
 
 
 def AlignGlobalLS(s1: bytes, s2: bytes, a, indelPenalty: int):
@@ -190,9 +215,9 @@ def AlignGlobalLS(s1: bytes, s2: bytes, a, indelPenalty: int):
     (panics, alternate tie-breaks); this one returns exactly AlignGlobal's result, which is what
     its author's disabled test asks for (align_test.go:55-66).  Pairs of LONG_MIN_CELLS cells
     or more go to the long-mode kernels when their parameters allow it."""
-    if len(s1) * len(s2) >= LONG_MIN_CELLS and len(set(bytes(s2))) <= 64:
-        return AlignPairLong("global", s1, s2, a, indelPenalty)
-    return AlignPair("global", s1, s2, a, indelPenalty)
+    use_long = len(s1) * len(s2) >= LONG_MIN_CELLS and len(set(bytes(s2))) <= 64
+    sc, t1, t2 = _run_batch("global", [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty, long=use_long)
+    return sc[0], t1[0], t2[0]
 
 
 def _dyadic_scale(*vals, max_shift=6):

@@ -8,7 +8,12 @@ prefix of t, align_pair.go:184-195) on the GPU, the fragments lying in HBM once.
 the length of t's prefix inside the overlap); there is no traceback at all.
 
 This changes behaviour on purpose (an overlap may contain mismatches and gaps), which is why SURVEY ranks it last.
-On error-free reads it returns what AlignLong returns.
+On error-free reads WITHOUT repeated half-fragments it returns what AlignLong returns.  With repeats the two can
+differ in either direction: the reference takes the first verbatim occurrence of s's last half anywhere in t
+(strings.Index, align_long.go:41) without looking at t's prefix and ranks by that position, this code takes the
+leftmost best bottom-row cell of an overlap alignment, with score and half-length thresholds
+(tests/test_assembly.py::test_repeated_half_fragment_records_both_behaviours holds one fixture for each direction).
+Parity is unpinned beyond that: the reference has no test of AlignLong.
 """
 from __future__ import annotations
 

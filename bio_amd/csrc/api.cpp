@@ -611,8 +611,11 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
             while (pl->waves > 2 && ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, pl->waves, pl->nib) > 80 * 1024)
                 --pl->waves;
             if ((max_m + 3) / 4 >= 65536) pl->pipe = 0;  // progress word: 16 bits of column groups
+            // a large alphabet: two strip profiles do not fit a CU's LDS, one wavefront per bundle does
+            if (ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, pl->waves, pl->nib) > 160 * 1024) pl->pipe = 0;
         }
         if (!pl->pipe) {
+            pl->waves = 1;
             // bundles per block: whatever puts the most wavefronts on a CU (160 KB of LDS, at most 16 resident here)
             size_t best_waves_per_cu = 0;
             for (int w = 4; w >= 1; w >>= 1) {
@@ -1147,6 +1150,7 @@ extern "C" int bioalign_batch(bioalign_ctx *ctx, const bioalign_batch_t *in, bio
     for (int d = 0; d < D; ++d)
         if (rcs[d]) {
             ctx->err = errs[d];
+            ctx->code = rcs[d];
             return rcs[d];
         }
     return 0;
@@ -2349,6 +2353,7 @@ int all_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, const uint64_t *off
     for (int d = 0; d < D; ++d)
         if (rcs[d]) {
             ctx->err = errs[d];
+            ctx->code = rcs[d];
             return rcs[d];
         }
     return 0;

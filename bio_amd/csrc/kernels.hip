@@ -775,6 +775,11 @@ static hipError_t launch_dp(const BaDpParams &P, int waves, hipStream_t st)
     const uint32_t nbundles = P.bundle_end - P.bundle_begin;
     const uint32_t blocks = (nbundles + waves - 1) / waves;
     const size_t lds = ba_dp_linear_lds_bytes(P.nb, P.nb4, P.na_pad, R, waves);
+    if (lds > 64 * 1024) {  // large alphabets: more than 64 KB of dynamic LDS has to be asked for
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_dp_linear_kernel<MODE, R, K>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ae != hipSuccess) return ae;
+    }
     hipLaunchKernelGGL((ba_dp_linear_kernel<MODE, R, K>), dim3(blocks), dim3(waves * 64), lds, st, P);
     return hipGetLastError();
 }

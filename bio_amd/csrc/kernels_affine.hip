@@ -559,21 +559,34 @@ static hipError_t launch_dp_aff(const BaDpParams &P, int waves, int pipe, hipStr
     const uint32_t nbundles = P.bundle_end - P.bundle_begin;
     const size_t lds = ba_dp_affine_lds_bytes(P.nb, P.nb4, P.na_pad, R, waves, P.nib);
     const dim3 grid(pipe ? nbundles : (nbundles + waves - 1) / waves), block(waves * 64);
+    // more than 64 KB of dynamic LDS (large alphabets) has to be asked for, kernel by kernel
+    auto allow = [&](auto kernel) {
+        return lds > 64 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                               : hipSuccess;
+    };
+    hipError_t ae = hipSuccess;
     if (P.nib) {
         // the 4-bit profile exists for the modes with a free top row and 16-row strips (api.cpp picks it)
         if constexpr (R == 16 && (MODE == BA_LOCAL || MODE == BA_FITTING)) {
-            if (pipe)
+            if (pipe) {
+                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, true, true>)) != hipSuccess) return ae;
                 hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true, true>), grid, block, lds, st, P);
-            else
+            } else {
+                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, false, true>)) != hipSuccess) return ae;
                 hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false, true>), grid, block, lds, st, P);
+            }
             return hipGetLastError();
         }
         return hipErrorInvalidValue;
     }
-    if (pipe)
+    if (pipe) {
+        if ((ae = allow(&ba_dp_affine_kernel<MODE, R, true, false>)) != hipSuccess) return ae;
         hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true, false>), grid, block, lds, st, P);
-    else
+    } else {
+        if ((ae = allow(&ba_dp_affine_kernel<MODE, R, false, false>)) != hipSuccess) return ae;
         hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false, false>), grid, block, lds, st, P);
+    }
     return hipGetLastError();
 }
 
@@ -606,6 +619,11 @@ static hipError_t launch_trace_aff(const BaTraceParams &P, hipStream_t st)
     const uint32_t nbundles = P.bundle_end - P.bundle_begin;
     const uint32_t blocks = (nbundles + waves - 1) / waves;
     const size_t lds = ((size_t)((P.na * P.nb + 3) & ~3) + 128) * 4;
+    if (lds > 64 * 1024) {
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_trace_affine_kernel<MODE, R>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ae != hipSuccess) return ae;
+    }
     hipLaunchKernelGGL((ba_trace_affine_kernel<MODE, R>), dim3(blocks), dim3(waves * 64), lds, st, P);
     return hipGetLastError();
 }

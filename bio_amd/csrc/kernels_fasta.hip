@@ -2,7 +2,7 @@
 // uint64 offsets), without a host pass over the bytes.  SURVEY.md 8(f) rank 1: the step before the DP path.
 //
 // Semantics: ReadFASTA, reference fasta.go:55-84 -- split at '\n', bytes.TrimSpace on every line (ASCII white
-// space here: \t \n \v \f \r and space), blank lines skipped, '>' opens a record (also one with no data),
+// space here: \t \n \v \f \r, space and the UTF-8 encoded Unicode spaces of Go's unicode.IsSpace), blank lines skipped, '>' opens a record (also one with no data),
 // other lines are appended to the last record, data before the first header is the error "No header".
 //
 // HBM-bound byte work, five small kernels:
@@ -29,6 +29,34 @@ __device__ __forceinline__ uint32_t fa_newline_bits(uint32_t v)
 }
 
 __device__ __forceinline__ bool fa_is_space(uint8_t c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+// bytes.TrimSpace (fasta.go:63) also trims UTF-8 encoded Unicode white space (unicode.IsSpace): U+0085, U+00A0, U+1680,
+// U+2000..U+200A, U+2028, U+2029, U+202F, U+205F, U+3000; anything else above 0x7f ends the trimming
+__device__ __forceinline__ bool fa_space3(uint8_t a, uint8_t b, uint8_t c)
+{
+    if (a == 0xE1) return b == 0x9A && c == 0x80;
+    if (a == 0xE2) return (b == 0x80 && (c <= 0x8A ? c >= 0x80 : (c == 0xA8 || c == 0xA9 || c == 0xAF))) || (b == 0x81 && c == 0x9F);
+    if (a == 0xE3) return b == 0x80 && c == 0x80;
+    return false;
+}
+// bytes of the white-space rune that starts at text[b] / that ends at text[t - 1], the line being [b, t); 0: none
+__device__ __forceinline__ int fa_space_at(const uint8_t *text, uint64_t b, uint64_t t)
+{
+    const uint8_t c = text[b];
+    if (fa_is_space(c)) return 1;
+    if (c < 0x80) return 0;
+    if (c == 0xC2 && b + 1 < t && (text[b + 1] == 0x85 || text[b + 1] == 0xA0)) return 2;
+    if (b + 2 < t && fa_space3(c, text[b + 1], text[b + 2])) return 3;
+    return 0;
+}
+__device__ __forceinline__ int fa_space_before(const uint8_t *text, uint64_t b, uint64_t t)
+{
+    const uint8_t c = text[t - 1];
+    if (fa_is_space(c)) return 1;
+    if (c < 0x80) return 0;
+    if (t - b >= 2 && text[t - 2] == 0xC2 && (c == 0x85 || c == 0xA0)) return 2;
+    if (t - b >= 3 && fa_space3(text[t - 3], text[t - 2], c)) return 3;
+    return 0;
+}
 
 // block-wide exclusive scan of one value per thread (256 threads); returns the prefix, *total = block sum
 __device__ __forceinline__ uint32_t fa_block_scan(uint32_t v, uint32_t *lds4, uint32_t *total)
@@ -209,10 +237,10 @@ __global__ void __launch_bounds__(256) fa_classify_kernel(BaFastaParams P)
             if (terminated ? raw > P.line_limit : raw >= P.line_limit) atomicMin(P.too_long, (unsigned long long)l);
             if (terminated && tt > bb && last[q] == '\r') --tt;
         } else {
-            if (fa_is_space(first[q]))
-                while (bb < tt && fa_is_space(P.text[bb])) ++bb;
-            if (fa_is_space(last[q]))
-                while (tt > bb && fa_is_space(P.text[tt - 1])) --tt;
+            if (fa_is_space(first[q]) || first[q] >= 0x80)
+                for (int k; bb < tt && (k = fa_space_at(P.text, bb, tt)) != 0;) bb += k;
+            if (fa_is_space(last[q]) || last[q] >= 0x80)
+                for (int k; tt > bb && (k = fa_space_before(P.text, bb, tt)) != 0;) tt -= k;
         }
         const bool blank = (tt == bb);
         const bool header = !blank && (bb == b[q] ? first[q] : P.text[bb]) == '>';

@@ -129,6 +129,8 @@ typedef struct {
 
 /* Opens the engine on the given HIP devices (NULL / 0 = device 0 only). */
 bioalign_ctx *bioalign_create(const int *device_ids, int n_devices);
+/* Closes the engine.  Plans, fasta objects and stripes made from a context hold a pointer to it: destroy them
+ * BEFORE the context (destroying one afterwards reads freed memory). */
 void bioalign_destroy(bioalign_ctx *ctx);
 /* Message of the last failure on this context (or of a failed create when ctx is NULL). */
 const char *bioalign_last_error(const bioalign_ctx *ctx);

@@ -967,6 +967,37 @@ int64_t bo_batch(int kind, int mode, const uint8_t *s1, const uint64_t *s1_off,
  * ReadFASTA, fasta.go:55-84
  * ------------------------------------------------------------------------- */
 static int bo_is_space(uint8_t c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+/* bytes.TrimSpace (fasta.go:63; Go standard library, bytes.TrimSpace -> unicode.IsSpace) trims UTF-8 encoded Unicode
+ * white space as well: U+0085, U+00A0 and category Z -- U+1680, U+2000..U+200A, U+2028, U+2029, U+202F, U+205F,
+ * U+3000.  A byte sequence that is not one of these encodings (or is cut short) decodes to something that is not
+ * white space and ends the trimming. */
+static int bo_space3(uint8_t a, uint8_t b, uint8_t c)
+{
+    if (a == 0xE1) return b == 0x9A && c == 0x80;
+    if (a == 0xE2) return (b == 0x80 && (c <= 0x8A ? c >= 0x80 : (c == 0xA8 || c == 0xA9 || c == 0xAF))) || (b == 0x81 && c == 0x9F);
+    if (a == 0xE3) return b == 0x80 && c == 0x80;
+    return 0;
+}
+/* bytes of the white-space rune that starts at text[b] (line is [b, t)); 0: none */
+static int bo_space_at(const uint8_t *text, uint64_t b, uint64_t t)
+{
+    uint8_t c = text[b];
+    if (bo_is_space(c)) return 1;
+    if (c < 0x80) return 0;
+    if (c == 0xC2 && b + 1 < t && (text[b + 1] == 0x85 || text[b + 1] == 0xA0)) return 2;
+    if (b + 2 < t && bo_space3(c, text[b + 1], text[b + 2])) return 3;
+    return 0;
+}
+/* bytes of the white-space rune that ends at text[t - 1] */
+static int bo_space_before(const uint8_t *text, uint64_t b, uint64_t t)
+{
+    uint8_t c = text[t - 1];
+    if (bo_is_space(c)) return 1;
+    if (c < 0x80) return 0;
+    if (t - b >= 2 && text[t - 2] == 0xC2 && (c == 0x85 || c == 0xA0)) return 2;
+    if (t - b >= 3 && bo_space3(text[t - 3], text[t - 2], c)) return 3;
+    return 0;
+}
 
 int64_t bo_read_fasta(const uint8_t *text, uint64_t len, uint8_t *seq, uint64_t *off, uint64_t *hdr_begin,
                       uint64_t *hdr_len)
@@ -978,8 +1009,8 @@ int64_t bo_read_fasta(const uint8_t *text, uint64_t len, uint8_t *seq, uint64_t 
         uint64_t e = pos;
         while (e < len && text[e] != '\n') ++e;
         uint64_t b = pos, t = e;               /* bytes.TrimSpace (fasta.go:63) */
-        while (b < t && bo_is_space(text[b])) ++b;
-        while (t > b && bo_is_space(text[t - 1])) --t;
+        for (int k; b < t && (k = bo_space_at(text, b, t)) != 0;) b += k;
+        for (int k; t > b && (k = bo_space_before(text, b, t)) != 0;) t -= k;
         if (t > b) {                           /* blank lines are skipped (fasta.go:65-66) */
             if (text[b] == '>') {              /* new record (fasta.go:67-71) */
                 found_header = 1;

@@ -61,6 +61,39 @@ def test_host_merge_logic_with_oracle_overlaps():
     assert bio_amd.AlignLongOverlap([]) == b"" and bio_amd.AlignLongOverlap([b"ACGT"]) == b"ACGT"
 
 
+def test_repeated_half_fragment_records_both_behaviours():
+    # A 30-base repeat R inside the genome (A + R + B + R + C, 60-base reads every 20 bases).  The reference looks for the
+    # last half of a read verbatim anywhere in another read (strings.Index, align_long.go:41) and does not check the
+    # prefix; AlignLongOverlap uses overlap alignments with thresholds.  On repeats the two differ, in both directions;
+    # these two fixtures record what each does (the claim "same result on error-free reads" was too strong).
+    import bio_amd
+
+    al = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def fixture(seed, off):
+        rng = np.random.default_rng(seed)
+        R = al[rng.integers(0, 4, 30)].tobytes()
+        A = al[rng.integers(0, 4, 130 + off)].tobytes()
+        B = al[rng.integers(0, 4, 110)].tobytes()
+        Cc = al[rng.integers(0, 4, 120 - off)].tobytes()
+        genome = A + R + B + R + Cc
+        reads = [genome[s:s + 60] for s in range(0, len(genome) - 60 + 1, 20)]
+        order = rng.permutation(len(reads))
+        return genome, [reads[k] for k in order]
+
+    # the repeat is exactly the last half of a read: the reference finds it in the wrong read and gives up; the
+    # alignment-based overlaps assemble the genome
+    genome, reads = fixture(0, 0)
+    assert O.AlignLong(reads) == b""
+    assert bio_amd.AlignLongOverlap(reads, end_cells=_oracle_cells) == genome
+    assert O.AlignLongOverlap(reads, O.MatchAligner(1, -1), 2) == genome
+    # the repeat straddles read halves: the reference assembles the genome, the alignment-based merge does not
+    genome, reads = fixture(6, 10)
+    assert O.AlignLong(reads) == genome
+    assert bio_amd.AlignLongOverlap(reads, end_cells=_oracle_cells) == b""
+    assert O.AlignLongOverlap(reads, O.MatchAligner(1, -1), 2) == b""
+
+
 @pytest.mark.gpu
 def test_gpu_assembly_matches_reference_and_oracle():
     import bio_amd

@@ -29,6 +29,23 @@ def test_oracle_documented_behaviour():
         O.ReadFASTA(b"ACGT\n>a\nAC\n")
 
 
+NBSP, NEL, OGHAM, EN_QUAD, HAIR, LSEP, PSEP, NNBSP, MMSP, IDEO = (
+    "\u00a0", "\u0085", "\u1680", "\u2000", "\u200a", "\u2028", "\u2029", "\u202f", "\u205f", "\u3000")
+
+
+def test_oracle_trims_unicode_white_space_like_go():
+    # bytes.TrimSpace (fasta.go:63) trims what unicode.IsSpace accepts, UTF-8 encoded, on both ends of a line; the
+    # reference's own tests hold no such line (parity pinned by Go's documented table, not by a fixture)
+    sp = "".join([NBSP, NEL, OGHAM, EN_QUAD, HAIR, LSEP, PSEP, NNBSP, MMSP, IDEO]).encode()
+    text = sp + b" >a\tx " + sp + b"\n" + IDEO.encode() + b"AC" + NBSP.encode() + b"GT" + HAIR.encode() + b" \r\n" + sp + b"\n>b\nT\n"
+    assert O.ReadFASTA(text) == [(b">a\tx", b"AC" + NBSP.encode() + b"GT"), (b">b", b"T")]
+    # not white space: U+200B (zero width space), U+FEFF, a lone continuation byte, a cut-off sequence
+    for junk in ("\u200b".encode(), "\ufeff".encode(), b"\xa0", b"\xe2\x80", b"\xc2"):
+        assert O.ReadFASTA(b">h\n" + junk + b"AC" + junk + b"\n") == [(b">h", junk + b"AC" + junk)]
+    # a line of Unicode spaces alone is blank; one that starts with them and then '>' is a header
+    assert O.ReadFASTA(b">h\nA\n" + sp + b"\n" + NBSP.encode() + b">i\nC") == [(b">h", b"A"), (b">i", b"C")]
+
+
 def test_id_and_desc_host_side():
     from bio_amd.fasta import FASTASeq
     f = FASTASeq(">db|123|abc example sequence", b"")
@@ -41,6 +58,17 @@ def _texts():
     alpha = b"ACGT"
     out = [EXAMPLE, b"", b"\n", b">only", b">a\n", b">a\r\nAC\r\nGT\r\n", b" \t>a  \n\t AC GT\t\n\n\n>b\n\n>c\nT",
            b">a\n" + b"A" * 70000 + b"\n", b">a\n" + b"\n" * 40000 + b"C\n", b">h\n" + b" " * 20000 + b"G" + b" " * 20000]
+    sp = [c.encode() for c in (NBSP, NEL, OGHAM, EN_QUAD, HAIR, LSEP, PSEP, NNBSP, MMSP, IDEO)]
+    out.append(b"".join(sp) + b" >a x " + b"".join(sp) + b"\n" + sp[9] + b"AC" + sp[0] + b"GT" + sp[4] + b" \r\n" + b"".join(sp) + b"\n>b\nT\n")
+    out.append(b">h\n\xa0AC\xa0\n\xe2\x80AC\xe2\x80\n\xc2\n" + "\u200b".encode() + b"G\n" + sp[1] + b">i\n\xc2\x85\xc2\n")
+    for k in range(3):  # Unicode white space sprinkled over the line ends
+        parts = []
+        for r in range(rng.randrange(50, 300)):
+            parts.append(rng.choice(sp + [b""]) + b">u%d" % r + rng.choice(sp + [b""]) + b"\n")
+            for _ in range(rng.randrange(0, 4)):
+                parts.append(rng.choice(sp + [b"", b" "]) + bytes(rng.choice(alpha) for _ in range(rng.randrange(0, 130))) +
+                             rng.choice(sp + [b"", b"\t"]) * rng.randrange(0, 3) + rng.choice([b"\n", b"\r\n"]))
+        out.append(b"".join(parts))
     for k in range(6):  # many records, line lengths around the 64-byte spans, text across several 16 KB chunks
         parts = []
         for r in range(rng.randrange(1, 400)):

@@ -182,3 +182,22 @@ def test_affine_pam250_keeps_the_byte_profile():
     s1s = [bytes(rng.choice(alpha) for _ in range(rng.randrange(1, 60))) for _ in range(100)]
     s2s = [bytes(rng.choice(alpha) for _ in range(rng.randrange(1, 60))) for _ in range(100)]
     _check_affine("local", s1s, s2s, bio_amd.Pam250, O.Pam250(), 10, 2)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_affine_hundred_column_symbols_large_lds(mode):
+    # as test_gpu_parity.test_hundred_column_symbols_large_lds, through the affine kernels (open 6, extend 1)
+    class Wide:
+        def Score(self, x, y):
+            return 4 if x == y else -((x * 5 + y * 3) % 4) - 1
+
+    table = np.zeros((256, 256), dtype=np.int32)
+    for x in range(256):
+        for y in range(256):
+            table[x, y] = 4 if x == y else -((x * 5 + y * 3) % 4) - 1
+    oa = O.TableAligner(table)
+    rng = random.Random(43)
+    s1s = [bytes(rng.randrange(46, 146) for _ in range(rng.randrange(20, 90))) for _ in range(70)]
+    s2s = [bytes(s1s[p][k] if rng.random() < 0.7 else rng.randrange(46, 146) for k in range(len(s1s[p]))) for p in range(70)]
+    s2s[0] = bytes(range(46, 146))
+    _check_affine(mode, s1s, s2s, Wide(), oa, 6, 1)

@@ -146,3 +146,56 @@ def test_asymmetric_user_aligner():
     s2s = [bytes(rng.randrange(97, 110) for _ in range(rng.randrange(1, 60))) for _ in range(80)]
     for mode in MODES:
         _check_batch(mode, s1s, s2s, Odd(), oa, 3)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_hundred_column_symbols_large_lds(mode):
+    # 100 distinct symbols on the column side: the strip profile of one wavefront is 100 KB of dynamic LDS, past the
+    # 64 KB a launch gets without asking (hipFuncSetAttribute in the launchers); linear gaps
+    class Wide:
+        def Score(self, x, y):
+            return 4 if x == y else -((x * 5 + y * 3) % 4) - 1
+
+    table = np.zeros((256, 256), dtype=np.int32)
+    for x in range(256):
+        for y in range(256):
+            table[x, y] = 4 if x == y else -((x * 5 + y * 3) % 4) - 1
+    oa = O.TableAligner(table)
+    rng = random.Random(41)
+    s1s = [bytes(rng.randrange(46, 146) for _ in range(rng.randrange(20, 90))) for _ in range(70)]
+    s2s = [bytes(s1s[p][k] if rng.random() < 0.7 else rng.randrange(46, 146) for k in range(len(s1s[p]))) for p in range(70)]
+    s2s[0] = bytes(range(46, 146))  # every one of the 100 symbols occurs
+    _check_batch(mode, s1s, s2s, Wide(), oa, 2)
+
+
+def test_nul_bytes_follow_align_pair_trace():
+    # align_pair.go:202-207: a symbol 0 is not appended to its trace, and the reversal loop then runs over t1's length
+    # for both traces (panics when t2 is too short for it); AlignGlobal / AlignLocal (align.go) append every byte
+    table = np.zeros((256, 256), dtype=np.int32)
+    for x in range(256):
+        for y in range(256):
+            table[x, y] = 2 if x == y else -1
+
+    class Eq:
+        def Score(self, x, y):
+            return 2 if x == y else -1
+
+    oa = O.TableAligner(table)
+    rng = random.Random(5)
+    checked = panicked = 0
+    for _ in range(60):
+        x = bytes(rng.choice(b"\x00AC") for _ in range(rng.randrange(1, 14)))
+        y = bytes(rng.choice(b"\x00AC") for _ in range(rng.randrange(1, 14)))
+        for mode in MODES:
+            try:
+                want = O.AlignPair(mode, x, y, oa, 1)
+            except O.GoPanic:
+                with pytest.raises(IndexError):
+                    bio_amd.AlignPair(mode, x, y, Eq(), 1)
+                panicked += 1
+                continue
+            assert bio_amd.AlignPair(mode, x, y, Eq(), 1) == want, (mode, x, y)
+            checked += 1
+        assert bio_amd.AlignGlobal(x, y, Eq(), 1) == O.AlignGlobal(x, y, oa, 1)
+        assert bio_amd.AlignLocal(x, y, Eq(), 1) == O.AlignLocal(x, y, oa, 1)
+    assert checked > 50 and panicked > 5

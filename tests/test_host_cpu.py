@@ -230,3 +230,17 @@ def test_shard_ranges_balance_and_cover():
     assert shard.shard_ranges([5], [5], 3).tolist()[-1] == 1
     b = shard.shard_ranges([10] * 8, [10] * 8, 8)
     assert b.tolist() == list(range(9))
+
+
+def test_align_pair_trace_quirk_on_nul_bytes():
+    # align_pair.go:197-216 restated on aligned traces (the kernels' output); checked against the oracle's trace() on the
+    # GPU (tests/test_gpu_parity.py::test_nul_bytes_follow_align_pair_trace)
+    from bio_amd.align import _trace_quirk
+    assert _trace_quirk(b"AC-T", b"ACGT") == (b"AC-T", b"ACGT")
+    assert _trace_quirk(None, None) == (None, None)
+    # one NUL in t1: walking back, t1 collects T C A and t2 collects T G C A; the loop swaps positions 0 and 2 of both
+    assert _trace_quirk(b"A\x00CT", b"ACGT") == (b"ACT", b"CGTA")
+    # t2 shorter than the index the loop uses: Go panics
+    with pytest.raises(IndexError):
+        _trace_quirk(b"ACGT", b"\x00\x00\x00T")
+    assert _trace_quirk(b"\x00", b"\x00") == (None, None)
