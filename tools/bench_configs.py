@@ -3,7 +3,9 @@
    python tools/bench_configs.py --config 3|4 [--pairs N] [--steps K]
 config 3: protein 300 x 300, local, affine (Blosum62, open 11, extend 1)
 config 4: DNA read 250 vs window 2000, fitting then overlap, affine (+1/-1, open 5, extend 1)
-Prints one JSON line per mode with DP-kernel and end-to-end GCUPS and checks a sample against the oracle."""
+Prints one JSON line per mode with DP-kernel and end-to-end GCUPS, the VALU roofline of the DP kernel (SURVEY.md 8d's
+algorithmic lane-ops per cell against 256 CU x 4 SIMD-32 x 2.4 GHz), a CPU leg (the oracle on the box's share of host
+cores, a bounded sample of the same pairs) and checks a sample against the oracle."""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,6 +19,7 @@ ap.add_argument("--pairs", type=int, default=0)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--check", type=int, default=300)
 ap.add_argument("--linear", action="store_true", help="same shapes with a linear gap (gap = open)")
+ap.add_argument("--cpu-sample", type=int, default=-1, help="pairs of the CPU leg (-1: about 10 s of oracle work, 0: none)")
 ap.add_argument("--dna", action="store_true", help="config 3 shapes and penalties with a 4-letter alphabet (+1/-1): the LDS profile is 5x smaller")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -56,6 +59,31 @@ for mode in modes:
     res = {"config": args.config, "mode": mode, "gap": [go, ge], "pairs": N, "cells": plan.cells, "ms": round(el * 1e3, 3),
            "gcups": round(plan.cells / el / 1e9, 1), "dp_ms": round(ms / max(n, 1) * (n / args.steps), 3),
            "dp_gcups": round(plan.cells / (ms / args.steps * 1e-3) / 1e9, 1), "workspace_gb": round(plan.workspace_bytes / 1e9, 2)}
+    # linear + direction 7 lane-ops per cell, affine + direction 13, local +2
+    ops = (13 if go != ge else 7) + (2 if mode == "local" else 0)
+    dp_s = ms / args.steps * 1e-3
+    import bench
+    res["roofline"] = {"bound": "valu", "ops_per_cell": ops, "achieved": round(ops * plan.cells / dp_s / 1e12, 3),
+                       "peak": round(bench.VALU_PEAK_LANE_OPS / 1e12, 2), "unit": "T lane-op/s (int32 VALU)",
+                       "frac": round(ops * plan.cells / dp_s / bench.VALU_PEAK_LANE_OPS, 4),
+                       "note": "algorithmic lane-ops (SURVEY.md 8d) over the DP kernel's HIP-event time; the kernel executes "
+                               "about 21 issue units per affine cell, 12 of them for its four decision bits (profiles/r02_notes.md)"}
+    ns = args.cpu_sample
+    if ns < 0:
+        ns = 6000 if args.config == 3 else 1200  # about 10 s on 16 threads
+    ns = min(ns, N)
+    if ns > 0:
+        from oracle import oracle as O
+        threads, share, host_cores, model = bench.host_cpu()
+        oa = O.Blosum62() if (args.config == 3 and not args.dna) else O.MatchAligner(1, -1)
+        kind = O.KIND_AFFINE if go != ge else (O.KIND_LOCAL if mode == "local" else O.KIND_PAIR)
+        t0c = time.perf_counter()
+        ref = O.batch(kind, mode, s1[:int(o1[ns])], o1[:ns + 1], s2[:int(o2[ns])], o2[:ns + 1], oa, go, ge, threads=threads)
+        dtc = time.perf_counter() - t0c
+        res["cpu_baseline"] = {"value": round(ref[4] / dtc / 1e9, 3), "unit": "GCUPS", "cores": threads, "kind": "port",
+                               "cpu_model": model, "host_cores": host_cores,
+                               "sample": f"{ns} of the same pairs, oracle (C restatement of the reference path), {dtc:.1f} s"}
+        assert np.array_equal(out["scores"][:ns].cpu().numpy(), ref[0][:ns]), "scores differ from the oracle on the CPU sample"
     if args.check:
         from oracle import oracle as O
         oa = O.Blosum62() if (args.config == 3 and not args.dna) else O.MatchAligner(1, -1)

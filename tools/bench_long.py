@@ -31,9 +31,19 @@ for r in range(args.reps):
     if best is None or eng.last_kernel_ms < best[0]:
         best = (eng.last_kernel_ms, wall)
 cells = args.n * args.m
+import bench
+# linear + direction 7 lane-ops per cell, local +2, against the full-rate int32 VALU peak
+OPS = 7 + (2 if args.mode == "local" else 0)
+def roofline(ms):
+    return {"bound": "valu", "ops_per_cell": OPS, "achieved": round(OPS * cells / (ms * 1e-3) / 1e12, 3),
+            "peak": round(bench.VALU_PEAK_LANE_OPS / 1e12, 2), "unit": "T lane-op/s (int32 VALU)",
+            "frac": round(OPS * cells / (ms * 1e-3) / bench.VALU_PEAK_LANE_OPS, 4),
+            "note": "one pair is latency-bound (a strip's step is a serial chain, profiles/r02_notes.md): the fraction says how "
+                    "far a single matrix is from what 1M independent pairs reach, not that issue slots are the limit"}
 if args.score_only:
     print(json.dumps({"config": 5, "mode": args.mode, "n": args.n, "m": args.m, "cells": cells, "score": int(scores[0]), "score_only": True,
-                      "kernel_ms": round(best[0], 3), "kernel_gcups": round(cells / (best[0] * 1e-3) / 1e9, 1)}), flush=True)
+                      "kernel_ms": round(best[0], 3), "kernel_gcups": round(cells / (best[0] * 1e-3) / 1e9, 1),
+                      "roofline": roofline(best[0])}), flush=True)
     sys.exit(0)
 a, l = int(toff[0]), int(tlen[0])
 x, y = t1[a:a + l], t2[a:a + l]
@@ -45,7 +55,7 @@ assert resc == int(scores[0]), (resc, int(scores[0]))
 res = {"config": 5, "mode": args.mode, "n": args.n, "m": args.m, "cells": cells, "score": int(scores[0]), "trace_len": l,
        "kernel_ms": round(best[0], 3), "kernel_gcups": round(cells / (best[0] * 1e-3) / 1e9, 1),
        "wall_ms_incl_alloc_copies": round(best[1] * 1e3, 1), "gen_s": round(gen, 1),
-       "checks": "trace spells both inputs; rescoring the trace = score"}
+       "checks": "trace spells both inputs; rescoring the trace = score", "roofline": roofline(best[0])}
 if args.oracle_prefix and args.mode == "global":
     from oracle import oracle as O
     k = min(args.oracle_prefix, args.n, args.m)
@@ -57,4 +67,9 @@ if args.oracle_prefix and args.mode == "global":
     dt = time.time() - t0
     assert int(col[0][-1]) == sck, (int(col[0][-1]), sck)
     res["oracle_prefix"] = f"{k} x {k}: score {sck} = oracle two-column pass ({k * k / dt / 1e9:.3f} GCUPS on 1 core)"
+    threads, share, host_cores, model = bench.host_cpu()
+    res["cpu_baseline"] = {"value": round(k * k / dt / 1e9, 3), "unit": "GCUPS", "cores": 1, "kind": "port", "cpu_model": model,
+                           "host_cores": host_cores,
+                           "sample": f"score-only two-column pass (align_linear.go:122-145 restated) on the {k} x {k} prefix pair; "
+                                     "the full-matrix path needs 160 GB at 100k x 100k"}
 print(json.dumps(res), flush=True)

@@ -8,7 +8,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   mkdir -p gpurun_out/$tag/p$i
-  timeout -s KILL 240 rocprofv3 --pmc $set --output-format csv -d gpurun_out/$tag/p$i -- python3 tools/bench_configs.py "$@" --steps 1 --check 0 > gpurun_out/$tag/p$i/log.txt 2>&1 || { echo "pass $i failed"; tail -5 gpurun_out/$tag/p$i/log.txt; exit 1; }
+  timeout -s KILL 240 rocprofv3 --pmc $set --output-format csv -d gpurun_out/$tag/p$i -- python3 tools/bench_configs.py "$@" --steps 1 --check 0 --cpu-sample 0 > gpurun_out/$tag/p$i/log.txt 2>&1 || { echo "pass $i failed"; tail -5 gpurun_out/$tag/p$i/log.txt; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections
