@@ -5,7 +5,7 @@ hand-written HIP kernels + a C ABI (include/bioalign.h) + this thin host mirror.
 """
 from .subst_matrix import (Blosum62, MatchAligner, NewSubstMatrix, Pam250,  # noqa: F401
                            SubstMatrix, score_table)
-from .align import (AlignAffineBatch, AlignGlobal, AlignGlobalAffine, AlignGlobalLS,  # noqa: F401
+from .align import (AlignAffineBatch, AlignAffinePairLong, AlignGlobal, AlignGlobalAffine, AlignGlobalLS,  # noqa: F401
                     AlignLocal, AlignPair, AlignPairBatch, AlignPairLong, ConstantGap, LinearGap,
                     engine, pack_sequences, set_engine)
 from . import _native  # noqa: F401

@@ -220,6 +220,16 @@ def AlignGlobalLS(s1: bytes, s2: bytes, a, indelPenalty: int):
     return sc[0], t1[0], t2[0]
 
 
+def AlignAffinePairLong(mode: str, s1: bytes, s2: bytes, a, gapOpenPenalty: int, gapExtendPenalty: int):
+    """AlignAffineBatch for ONE long pair, computed by the intra-sequence wavefront kernels with Gotoh's three
+    levels in registers (bioalign_long with open != extend): same result as the batch kernels, four modes,
+    <= 64 distinct column symbols."""
+    if mode not in _native.MODES:
+        return -1, None, None
+    sc, t1, t2 = _run_batch(mode, [bytes(s1)], [bytes(s2)], a, gapOpenPenalty, gapExtendPenalty, long=True)
+    return sc[0], t1[0], t2[0]
+
+
 def _dyadic_scale(*vals, max_shift=6):
     """The smallest power of two that turns every value into a whole number, or None."""
     for e in range(max_shift + 1):
@@ -242,5 +252,8 @@ def AlignGlobalAffine(s1: bytes, s2: bytes, a, gapOpenPenalty: float, gapExtendP
     if scale is None:
         raise ValueError("AlignGlobalAffine on the GPU path needs penalties that are multiples of 1/64 "
                          f"(got open {go!r}, extend {ge!r}): the kernels are exact integer Gotoh")
-    sc, t1, t2 = _run_batch("global", [bytes(s1)], [bytes(s2)], a, int(go * scale), int(ge * scale), scale=scale)
+    # (a linear gap, open == extend, stays on the batch kernels: bioalign_long would take it for AlignPair's recurrence)
+    use_long = len(s1) * len(s2) >= LONG_MIN_CELLS and len(set(bytes(s2))) <= 64 and go != ge
+    sc, t1, t2 = _run_batch("global", [bytes(s1)], [bytes(s2)], a, int(go * scale), int(ge * scale), scale=scale,
+                            long=use_long)
     return sc[0] / scale, t1[0], t2[0]

@@ -1162,6 +1162,8 @@ extern "C" int bioalign_batch(bioalign_ctx *ctx, const bioalign_batch_t *in, bio
 extern "C" int ba_long_rows_per_lane(int K);
 extern "C" int ba_long_strips_per_group(void);
 extern "C" hipError_t ba_launch_long(const BaLongParams &P, int mode, int T, int K, int phases, hipStream_t st);
+extern "C" int ba_long_affine_rows_per_lane(void);
+extern "C" hipError_t ba_launch_long_affine(const BaLongParams &P, int mode, int T, int phases, hipStream_t st);
 
 namespace {
 
@@ -1181,6 +1183,8 @@ struct DevBuf {
 
 int long_geometry(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t n, uint64_t m, int *K_out, int *T_out,
                   std::vector<uint32_t> *rowprof);
+int long_geometry_affine(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t n, uint64_t m, int *K_out, int *T_out,
+                         std::vector<uint32_t> *rowprof);
 
 // one pair, n >= 1 and m >= 1, results into slot p of `out`
 int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *out, uint64_t p, float *dp_ms)
@@ -1188,10 +1192,12 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     const uint64_t a1 = in->s1_off[p], a2 = in->s2_off[p];
     const uint64_t n = in->s1_off[p + 1] - a1, m = in->s2_off[p + 1] - a2;
     const int g = in->gap_open;
+    const bool affine = in->gap_open != in->gap_extend;  // three-level Gotoh (align_affine.go) on the long-mode mapping
     const bool traces = !(in->flags & BIOALIGN_SCORE_ONLY);
     int K = 0, T = 0;
     std::vector<uint32_t> rowprof;
-    if (int rc0 = long_geometry(ctx, in, n, m, &K, &T, &rowprof)) return rc0;
+    if (int rc0 = affine ? long_geometry_affine(ctx, in, n, m, &K, &T, &rowprof) : long_geometry(ctx, in, n, m, &K, &T, &rowprof))
+        return rc0;
     const int cpd = 32 / (T * K);
     const uint64_t rs = 64ull * T;
     const uint64_t strips = (n + rs - 1) / rs;
@@ -1201,7 +1207,8 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     HIP_TRY(ctx, hipSetDevice(ctx->devices[0]));
     DevBuf d_s1, d_s2, d_prof, d_c1, d_c2, d_tab, d_bnd, d_res, d_misc, d_t1, d_t2, d_ops, d_lmax;
     int rc;
-    if (in->mode == BIOALIGN_LOCAL && (rc = d_lmax.alloc(ctx, strips * 64 * 4))) return rc;
+    // local: per lane its largest score (affine: per row its largest true score and the step it was reached at)
+    if (in->mode == BIOALIGN_LOCAL && (rc = d_lmax.alloc(ctx, strips * 64 * 4 * (affine ? 2 * (size_t)T : 1)))) return rc;
     if ((rc = d_s1.alloc(ctx, n + 16)) || (rc = d_s2.alloc(ctx, m + 16)) || (rc = d_prof.alloc(ctx, rowprof.size() * 4)) ||
         (rc = d_c1.alloc(ctx, 256)) || (rc = d_c2.alloc(ctx, 256)) || (rc = d_tab.alloc(ctx, (size_t)in->na * in->nb * 4)) ||
         (rc = d_bnd.alloc(ctx, nsuper * ((m + 15) / 16 * 16) * 8 + 256)) ||
@@ -1237,6 +1244,7 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     P.code2 = d_c2.as<uint8_t>();
     P.pad_code = in->na;
     P.gap = g;
+    P.gap_ext = in->gap_extend;
     P.bnd = d_bnd.as<int32_t>();
     P.resid = d_res.as<uint32_t>();
     // misc: [0] status, [8] score, [16] t_off, [24] t_len, [32..43] walk
@@ -1264,7 +1272,8 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     HIP_TRY(ctx, hipEventCreate(&e0));
     HIP_TRY(ctx, hipEventCreate(&e1));
     HIP_TRY(ctx, hipEventRecord(e0, st));
-    hipError_t le = ba_launch_long(P, in->mode, T, K, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK, st);
+    hipError_t le = affine ? ba_launch_long_affine(P, in->mode, T, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK, st)
+                           : ba_launch_long(P, in->mode, T, K, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK, st);
     if (le == hipSuccess) le = hipEventRecord(e1, st);
     uint64_t misc[8] = {0};
     if (le == hipSuccess) le = hipMemcpyAsync(misc, d_misc.p, 64, hipMemcpyDeviceToHost, st);
@@ -1356,6 +1365,44 @@ int long_geometry(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t n, uin
     int8_t *tab = reinterpret_cast<int8_t *>(rowprof->data());
     for (int a = 0; a < in->na; ++a)
         for (int b = 0; b < in->nb; ++b) tab[(size_t)a * in->nb + b] = (int8_t)(in->score_table[a * in->nb + b] + bias);
+    return 0;
+}
+
+// Affine gaps in long mode: the cell of kernels_affine.hip (levels biased by ext*(i+j), profile byte = w + open + ext,
+// four decision bits per cell).  Rows of the first strip that lie above the matrix: -128 against everything, or `open`
+// in the modes with a free top row (they reproduce H'(0, j) = ext*j through their diagonal, as in the batch planner).
+int long_geometry_affine(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t n, uint64_t m, int *K_out, int *T_out,
+                         std::vector<uint32_t> *rowprof)
+{
+    const int go = in->gap_open, ge = in->gap_extend;
+    if (ge < 0 || go < ge)
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "gap penalties (%d, %d): the affine kernels need open >= extend >= 0", go, ge);
+    if (go > 127) return ctx->fail(BIOALIGN_EUNSUPPORTED, "gap_open %d does not fit the int8 profile", go);
+    if (in->nb > 64)
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode keeps a strip profile of 256 bytes per column symbol and wavefront "
+                                                "in LDS: at most 64 distinct column symbols (got %d)", in->nb);
+    int wmax = 0;
+    for (int i = 0; i < in->na * in->nb; ++i) {
+        const int64_t v = (int64_t)in->score_table[i] + go + ge;
+        if (v < -127 || v > 127)
+            return ctx->fail(BIOALIGN_EUNSUPPORTED, "score %d with gaps (%d, %d) does not fit the int8 row profile",
+                             in->score_table[i], go, ge);
+        wmax = std::max(wmax, in->score_table[i]);
+    }
+    // working-space magnitudes stay far from the levels' minus infinity (-2^28)
+    if ((n + m + 2) * (uint64_t)(128 + go + ge) >= (1ull << 27))
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "pair too long for the affine long-mode kernels' 32-bit working scores");
+    if (in->mode == BIOALIGN_LOCAL && (std::min(n, m) + 1) * (uint64_t)std::max(wmax, 1) >= (1ull << 31))
+        return ctx->fail(BIOALIGN_EUNSUPPORTED, "local scores do not fit 32 bits");
+    *K_out = 4;
+    *T_out = ba_long_affine_rows_per_lane();
+    const bool top_free = in->mode == BIOALIGN_LOCAL || in->mode == BIOALIGN_FITTING;
+    const size_t bytes = (size_t)(in->na + 1) * in->nb;
+    rowprof->assign((bytes + 3) / 4, 0x80808080u);
+    int8_t *tab = reinterpret_cast<int8_t *>(rowprof->data());
+    for (int a = 0; a < in->na; ++a)
+        for (int b = 0; b < in->nb; ++b) tab[(size_t)a * in->nb + b] = (int8_t)(in->score_table[a * in->nb + b] + go + ge);
+    for (int b = 0; b < in->nb; ++b) tab[(size_t)in->na * in->nb + b] = (int8_t)(top_free ? go : -128);
     return 0;
 }
 
@@ -1719,8 +1766,6 @@ extern "C" int bioalign_long(bioalign_ctx *ctx, const bioalign_batch_t *in, bioa
     if (traces && (!out->t1 || !out->t2 || !out->t_off || !out->t_len))
         return ctx->fail(BIOALIGN_EINVAL, "trace buffers are required unless BIOALIGN_SCORE_ONLY is set");
     if (kernel_ms) *kernel_ms = 0.f;
-    if (in->gap_open != in->gap_extend)
-        return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode covers linear gaps only (affine: use bioalign_batch)");
     if (in->gap_open < 0) return ctx->fail(BIOALIGN_EUNSUPPORTED, "negative gap penalty %d", in->gap_open);
     for (uint64_t p = 0; p < N; ++p) {
         const uint64_t n = in->s1_off[p + 1] - in->s1_off[p], m = in->s2_off[p + 1] - in->s2_off[p];
@@ -1737,7 +1782,8 @@ extern "C" int bioalign_long(bioalign_ctx *ctx, const bioalign_batch_t *in, bioa
             // column stripes over the context's devices when the residue words (K bits per cell, K <= 8) may not
             // fit one device, or when BIOALIGN_LONG_STRIPES asks for them
             // (local mode runs unstriped: its end cell is a maximum over the whole matrix)
-            int stripes = in->mode == BIOALIGN_LOCAL ? 1 : (int)env_u64("BIOALIGN_LONG_STRIPES", 0);
+            // (affine gaps too: the stripes hand over one value per row, the affine kernels need two)
+            int stripes = (in->mode == BIOALIGN_LOCAL || in->gap_open != in->gap_extend) ? 1 : (int)env_u64("BIOALIGN_LONG_STRIPES", 0);
             if (stripes == 0 && ctx->devices.size() > 1) {
                 size_t free_b = 0, total_b = 0;
                 HIP_TRY(ctx, hipSetDevice(ctx->devices[0]));

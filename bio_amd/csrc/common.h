@@ -111,7 +111,8 @@ struct BaLongParams {
     const uint32_t *rowprof;       // signed bytes [na + 1][nb]: w(a, b) + 2g; row na = padding (-128 against everything)
     const uint8_t *code1, *code2;  // [256] byte -> dense code
     int pad_code;                  // = na
-    int gap;
+    int gap;                       // linear: the gap penalty; affine: gap open
+    int gap_ext;                   // affine: gap extend (the affine kernels are chosen by the host, not by this field)
     int32_t *bnd;                  // [nsuper][bnd_stride] granules {working-space score, tag}, 8 bytes each: the bottom row of every
                                    // workgroup's last strip; zeroed before the launch (tag 0 = not there yet)
     uint32_t bnd_stride;           // granules per row: m rounded up to 16 (a sub-block of 16 columns is one whole 128-byte line)
@@ -119,6 +120,7 @@ struct BaLongParams {
     uint32_t *resid;               // [strips][words_per_strip][64 lanes]
     uint32_t *status;              // != 0: a wait ran out (should never happen)
     int32_t *lane_max;             // local mode: [strips][64] the largest score each lane saw in its T rows
+                                   // (affine: [strips][64][T][2] = largest true score of the row, step it was first seen at)
     // traceback
     const int32_t *table;          // na * nb scores as the caller gave them
     int nb;

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "device_helpers.h"
@@ -76,6 +77,7 @@ struct BaLongWaveLds {
     uint32_t ohw[128];   // column symbols as byte offsets into a lane's strip profile (4 * code), window of two 64-column
                          // blocks [previous | current]: lane l at step k of a block reads slot 64 + k - l
     int32_t dummy[128];  // where the lanes other than 63 put their (not yet final) bottom-row values
+    int32_t dummy_f[128];  // affine: the same for F'
 };
 
 #define BA_LONG_RING (BA_LONG_RB * 64)  // columns a hand-over ring holds
@@ -109,6 +111,64 @@ __device__ __forceinline__ void ba_long_step(int (&h)[T], uint32_t &acc, int top
     }
 }
 
+#define BA_LONG_NEG (-(1 << 28))  // minus infinity of the E / F levels (align_affine.go:36-37, 45-46, 63-64)
+
+// push the sign bit of t into the bottom of a bit field
+__device__ __forceinline__ uint32_t ba_long_push_sign(uint32_t acc, int t)
+{
+    return __builtin_amdgcn_alignbit(acc, (uint32_t)t, 31);
+}
+
+// Affine gaps (three-level Gotoh, align_affine.go:44-103), the cell of kernels_affine.hip on the long-mode mapping:
+// every level biased by ext*(i+j), a lane keeps hq = H' - c (c = open - ext) and E' of its T rows; F' travels down the
+// column -- from the lane above through a second DPP shift, from the strip above through a second ring.  Four decision
+// bits per cell (nF, nD, oE, oF, see kernels_affine.hip), pushed as one nibble: the K = 4 layout of the residues.
+// Local: the zero level of a cell is ext*(i+j) (`fl`, one add per row); the best cell is kept per ROW as (largest true
+// score, step it was first reached at): strict '>' keeps the first column, and rows are compared afterwards.
+template <int T, bool CHECK, int MODE>
+__device__ __forceinline__ void ba_long_step_aff(int (&hq)[T], int (&e)[T], uint32_t &acc, int top, int ftop, int diag0,
+                                                 uint32_t pw, bool active, int c, int ge, int fl, int (&rmax)[T],
+                                                 int (&rstep)[T], int t, int &fout)
+{
+    int up = top, diag = diag0, f = ftop;
+#pragma unroll
+    for (int r = 0; r < T; ++r) {
+        const int eo = e[r], left = hq[r];
+        const int en = max(eo, left);
+        const int fn = max(f, up);
+        const int d = diag + ba_sbyte(pw, r);
+        int H = ba_max3(en, fn, d);
+        if (MODE == BA_LOCAL) {
+            fl += ge;
+            H = max(H, fl);
+        }
+        uint32_t cb = 0;
+        cb = ba_long_push_sign(cb, fn - H);   // nF
+        cb = ba_long_push_sign(cb, d - H);    // nD
+        cb = ba_long_push_sign(cb, eo - en);  // oE
+        cb = ba_long_push_sign(cb, f - fn);   // oF
+        acc = __builtin_amdgcn_alignbit(cb, acc, 4);
+        int hn = H - c, e_new = en, f_new = fn;
+        if (CHECK && !active) {
+            hn = left;
+            e_new = eo;
+            f_new = f;
+        }
+        if (MODE == BA_LOCAL) {
+            const int ht = H - fl;
+            const bool better = (!CHECK || active) && ht > rmax[r];
+            rmax[r] = better ? ht : rmax[r];
+            rstep[r] = better ? t : rstep[r];
+        }
+        diag = left;
+        hq[r] = hn;
+        e[r] = e_new;
+        f = f_new;
+        up = hn;
+    }
+    fout = f;
+}
+
 // The DP of one pair.  A workgroup is BA_LONG_W consecutive strips, one wavefront each (one per SIMD of a CU), plus one
 // helper wavefront; compute wave w of workgroup S runs strip s = S*W + w - pad (pad: phantom waves above the matrix in
 // the first workgroup, so that the last strip is the last wave of the last workgroup).
@@ -136,15 +196,21 @@ __device__ __forceinline__ void ba_long_step(int (&h)[T], uint32_t &acc, int top
 // MULTI: the grid holds the workgroups of several column stripes of one pair (P0.multi / P0.order); the workgroups
 // are ordered by the time they can start, which keeps every workgroup behind the two it waits for -- the one above it
 // in its own stripe and the one at its height in the stripe to its left.
-template <int MODE, int T, int K, bool MULTI>
+//
+// AFF: affine gaps (ba_long_step_aff): a hand-over carries two values per column, hq and F' -- a second LDS ring, and
+// in the HBM granule F' travels as an 8-bit offset from hq (F' <= hq + c always; anything below hq behaves like hq - 1),
+// next to a 24-bit tag.
+template <int MODE, int T, int K, bool MULTI, bool AFF>
 __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLongParams P0)
 {
+    static_assert(!AFF || (K == 4 && !MULTI), "affine: four decision bits per cell, unstriped");
     using G = BaLongGeom<T, K>;
     constexpr int RS = G::RS, CPD = G::CPD, W = BA_LONG_W, RING = BA_LONG_RING;
     extern __shared__ __align__(16) uint32_t dyn_lds[];  // strip profiles: [wave][column symbol][lane] dwords, then padding
     __shared__ uint32_t code2s[64];  // byte -> code of the column side, packed
     __shared__ BaLongWaveLds wl[W];
     __shared__ int32_t rings[W + 1][RING];
+    __shared__ int32_t rings_f[AFF ? W + 1 : 1][AFF ? RING : 1];  // affine: F' of the same columns
     __shared__ uint32_t prog_s[W + 1];   // columns of ring r that are final (all columns below this number)
     __shared__ uint32_t cons_s[W + 1];   // columns of ring r its reader is done with
     __shared__ uint32_t fail_s;          // a wait has run out somewhere in this workgroup
@@ -179,6 +245,22 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     const int b_left = (MODE == BA_OVERLAP) ? g : 0;  // Hs(i, 0) = b_left * i
     const int col0 = (int)P.col0;  // column stripes: my column 0 is column col0 of the matrix
     const uint32_t epoch = P.epoch;
+    // affine: H'(i, 0) and H'(0, j) (align_pair.go:110-113, 130-131, 158-159, 187-188 on the middle level, kernels_affine.hip)
+    constexpr bool top_free = (MODE == BA_LOCAL || MODE == BA_FITTING);
+    constexpr bool left_free = (MODE == BA_LOCAL || MODE == BA_OVERLAP);
+    const int ge = P.gap_ext, cc = P.gap - P.gap_ext;
+    auto aff_col0 = [&](int i) { return left_free ? ge * max(i, 0) : (i >= 1 ? -cc : 0); };
+    auto aff_row0 = [&](int j) { return top_free ? ge * j : (j >= 1 ? -cc : 0); };
+    // granule: {value, tag}; affine: {hq, tag << 8 | (F' - hq clamped to -1 .. 254) + 1}
+    constexpr uint32_t POISON = AFF ? 0x800000u : BA_LONG_POISON;
+    auto tag_of = [](unsigned long long gr) { return AFF ? (uint32_t)(gr >> 40) : (uint32_t)(gr >> 32); };
+    auto mk_gran = [](uint32_t tag, int v, int fv) -> unsigned long long {
+        if (AFF) {
+            const uint32_t delta = (uint32_t)(min(max(fv - v, -1), 254) + 1);
+            return ((unsigned long long)((tag << 8) | delta) << 32) | (uint32_t)v;
+        }
+        return ((unsigned long long)tag << 32) | (uint32_t)v;
+    };
 
     auto ld = [](uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto st = [](uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
@@ -207,6 +289,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     if (w == W) {
         const unsigned long long *bnd_in = reinterpret_cast<const unsigned long long *>(P.bnd) + (size_t)(S > 0 ? S - 1 : 0) * P.bnd_stride;
         int32_t *ring = rings[first_ring];
+        int32_t *ring_f = rings_f[AFF ? first_ring : 0];
         int done = 0;  // columns handed to the ring so far: a multiple of 16 until the end
         int idle = 0;
         while (done < m) {
@@ -220,21 +303,23 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int col = (b0 + q) * 64 + lane;
-                if (S == 0)
-                    gv[q] = ((unsigned long long)epoch << 32) | (uint32_t)(b_top * (col0 + col + 1));
+                if (S == 0)  // the top border in closed form (affine: row 0 of the middle level, F' = -inf)
+                    gv[q] = AFF ? mk_gran(epoch, aff_row0(col + 1) - cc, BA_LONG_NEG) : mk_gran(epoch, b_top * (col0 + col + 1), 0);
                 else
                     gv[q] = (q < cnt && col < m) ? __hip_atomic_load(bnd_in + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                 : ((unsigned long long)epoch << 32);
+                                                 : mk_gran(epoch, 0, 0);
             }
             // valid prefix, in columns from b0 * 64
             int prefix = 0;
             bool open = true, poisoned = false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t tag = (uint32_t)(gv[q] >> 32);
-                poisoned = poisoned || (q < cnt && __any(tag == (epoch | BA_LONG_POISON)));
+                const uint32_t tag = tag_of(gv[q]);
+                poisoned = poisoned || (q < cnt && __any(tag == (epoch | POISON)));
                 const unsigned long long ok = __ballot(tag == epoch);
                 if (q < cnt) ring[((b0 + q) * 64 + lane) & (RING - 1)] = (int32_t)(uint32_t)gv[q];
+                if (AFF && q < cnt)
+                    ring_f[((b0 + q) * 64 + lane) & (RING - 1)] = (int32_t)(uint32_t)gv[q] + (int)((uint32_t)(gv[q] >> 32) & 0xffu) - 1;
                 if (q < cnt && open) {
                     const int lead = ok == ~0ull ? 64 : (int)__builtin_ctzll(~ok);
                     prefix += lead;
@@ -272,6 +357,8 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     BaLongWaveLds &L = wl[w];
     const int32_t *ring_in = rings[w];
     int32_t *ring_out = rings[w + 1];
+    const int32_t *ring_f_in = rings_f[AFF ? w : 0];
+    int32_t *ring_f_out = rings_f[AFF ? w + 1 : 0];
     uint32_t *prog_in = &prog_s[w], *cons_in = &cons_s[w], *prog_out = &prog_s[w + 1], *cons_out = &cons_s[w + 1];
     const bool last_wave = (w == W - 1);  // my bottom row goes to the workgroup below (and to the traceback)
 
@@ -280,6 +367,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     const int i0 = n - (strips - s) * RS;
     const int32_t *left_col = P.left_col;  // column stripes: handed over by the stripe to the left
     auto first_col = [&](int i) {
+        if (AFF) return aff_col0(i) - cc;  // hq = H' - c
         if (MULTI && P.left_gran) return 0;  // (comes through the granules below)
         return left_col ? left_col[max(i, 0)] : b_left * max(i, 0);
     };
@@ -347,6 +435,17 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     int topprev = ba_wave_shr1(left_top, bottom);
     uint32_t acc = 0;
     int lmax = 0;  // local: the largest score of my rows so far
+    // affine: E' of my rows (align_affine.go:45-46: -inf in column 0), F' of my last row after the previous step, and
+    // (local) the best cell of every row
+    int e[T], rmax[T], rstep[T];
+#pragma unroll
+    for (int r = 0; r < T; ++r) {
+        e[r] = BA_LONG_NEG;
+        rmax[r] = 0;
+        rstep[r] = 0;
+    }
+    int bottom_f = BA_LONG_NEG;
+    const int fl_const = ge * (i0 + lane * T - lane + 1);  // zero level of the row above my first one at step t: this + ge * t
 
     const uint32_t *oh_me = L.ohw + 64 - lane;  // my window slot for step 0 of a block
 
@@ -362,8 +461,9 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
         for (; sent + 16 <= upto || (upto == m && sent < m); sent += 16) {
             const int col = sent + (lane & 15);
             if (lane < 16 && col < m) {
-                const uint32_t v = (uint32_t)ring_out[col & (RING - 1)];
-                __hip_atomic_store(bnd_out + col, ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int v = ring_out[col & (RING - 1)];
+                const int fv = AFF ? ring_f_out[col & (RING - 1)] : 0;
+                __hip_atomic_store(bnd_out + col, mk_gran(tag, v, fv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
@@ -374,6 +474,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
         L.ohw[64 + lane] = ohnext;
         if (b + 1 < nblk) ohnext = load_symbols(b + 1);
         const int32_t *tin_base = ring_in + (t0 & (RING - 1));
+        const int32_t *tinf_base = ring_f_in + (AFF ? (t0 & (RING - 1)) : 0);
         uint32_t *resid_blk = resid + (size_t)(t0 / CPD) * 64;
         // all lanes inside their column range for the whole block?
         const bool steady = (b >= 1) && (t0 + 64 <= m);
@@ -382,16 +483,20 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
         if (!last_wave && t0 + 1 > RING) wait_lds(cons_out, (uint32_t)(t0 + 1 - RING));
         int32_t *wp = (lane == 63) ? ring_out + ((t0 - 63) & (RING - 1)) : L.dummy + lane;
         int32_t *wp63 = (lane == 63) ? ring_out + (t0 & (RING - 1)) : L.dummy + lane;
+        int32_t *wpf = (AFF && lane == 63) ? ring_f_out + ((t0 - 63) & (RING - 1)) : L.dummy_f + lane;
+        int32_t *wpf63 = (AFF && lane == 63) ? ring_f_out + (t0 & (RING - 1)) : L.dummy_f + lane;
 
+        constexpr int TN = AFF ? 32 : 16;  // affine: tin[16 + k] = F' of the row above
         uint32_t ohA[16], ohB[16], pwA[16], pwB[16];
-        int tinA[16], tinB[16];
+        int tinA[TN], tinB[TN];
         // columns j*16 .. j*16+15 of the row above must be final (columns >= m never are: nobody reads them)
         auto need_cols = [&](int j) -> uint32_t { return (uint32_t)min(t0 + j * 16 + 16, m); };
-        auto fetch = [&](uint32_t (&oh)[16], int (&tin)[16], int j) {
+        auto fetch = [&](uint32_t (&oh)[16], int (&tin)[TN], int j) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 oh[k] = oh_me[j * 16 + k];
                 tin[k] = tin_base[j * 16 + k];
+                if (AFF) tin[(AFF ? 16 : 0) + k] = tinf_base[j * 16 + k];
             }
         };
         // the scores of my rows against the 16 column symbols of a sub-block: one dword of my strip profile each
@@ -399,8 +504,34 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
 #pragma unroll
             for (int k = 0; k < 16; ++k) pw[k] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(prof) + oh[k]);
         };
-        auto compute = [&](const uint32_t (&pw)[16], const int (&tin)[16], int j) {
-            if (steady) {
+        auto compute = [&](const uint32_t (&pw)[16], const int (&tin)[TN], int j) {
+            if (AFF) {
+                auto steps = [&](auto check) {
+                    constexpr bool CHECK = decltype(check)::value;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int t = t0 + j * 16 + k;
+                        if (!CHECK || t < total_steps) {
+                            const int top = ba_wave_shr1(tin[k], bottom);
+                            const int ftop = ba_wave_shr1(tin[(AFF ? 16 : 0) + k], bottom_f);
+                            const bool active = !CHECK || ((t >= lane) && (t - lane < m));
+                            int fout;
+                            ba_long_step_aff<T, CHECK, MODE>(h, e, acc, top, ftop, topprev, pw[k], active, cc, ge, fl_const + ge * t,
+                                                             rmax, rstep, t, fout);
+                            topprev = top;
+                            bottom = h[T - 1];
+                            bottom_f = fout;
+                            ba_lds_store((j * 16 + k == 63) ? wp63 : wp + j * 16 + k, bottom);
+                            ba_lds_store((j * 16 + k == 63) ? wpf63 : wpf + j * 16 + k, bottom_f);
+                            if ((k + 1) % CPD == 0) resid_blk[(size_t)((j * 16 + k) / CPD) * 64] = acc;
+                        }
+                    }
+                };
+                if (steady)
+                    steps(std::false_type{});
+                else
+                    steps(std::true_type{});
+            } else if (steady) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int top = ba_wave_shr1(tin[k], bottom);
@@ -435,7 +566,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
         // sub-block j with its inputs in (pw, tin); the inputs of sub-block j+1 are fetched into (ohn, tinn) before the
         // steps when the row above is known to be far enough, after them (waiting) otherwise, and its scores after the
         // steps (their addresses are the symbols just fetched)
-        auto stage = [&](const uint32_t (&pw)[16], const int (&tin)[16], uint32_t (&ohn)[16], int (&tinn)[16],
+        auto stage = [&](const uint32_t (&pw)[16], const int (&tin)[TN], uint32_t (&ohn)[16], int (&tinn)[TN],
                          uint32_t (&pwn)[16], int j, bool more) {
             // (compiler barriers, not fences: what orders the ring reads behind the counter read is the LDS itself,
             // which carries out one wavefront's operations in the order they were issued)
@@ -473,17 +604,25 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     // every column is final now
     const bool failed = ld(&fail_s) != 0;
     if (last_wave) {
-        send(m, failed ? (epoch | BA_LONG_POISON) : epoch);
+        send(m, failed ? (epoch | POISON) : epoch);
         if (failed) {  // nobody below may wait for what was sent with a good tag before the failure either
             for (int col = lane; col < m; col += 64)
-                __hip_atomic_store(bnd_out + col, (unsigned long long)(epoch | BA_LONG_POISON) << 32, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(bnd_out + col, mk_gran(epoch | POISON, 0, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane == 0) atomicAdd(P.status, 1u);
         }
     } else {
         publish(prog_out, (uint32_t)m);
     }
-    if (MODE == BA_LOCAL) P.lane_max[(size_t)s * 64 + lane] = lmax;
+    if (MODE == BA_LOCAL && !AFF) P.lane_max[(size_t)s * 64 + lane] = lmax;
+    if (MODE == BA_LOCAL && AFF) {
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            // (rows above the matrix score -ext*i against their zero level: they are not cells)
+            if (i0 + lane * T + r + 1 < 1) rmax[r] = 0;
+            P.lane_max[(((size_t)s * 64 + lane) * T + r) * 2 + 0] = rmax[r];
+            P.lane_max[(((size_t)s * 64 + lane) * T + r) * 2 + 1] = rstep[r];
+        }
+    }
     // column stripes: my last column is the next stripe's column 0
     if (P.right_col) {
 #pragma unroll
@@ -924,6 +1063,340 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
     }
 }
 
+// ----------------------------------------------------------------------------
+// traceback, long mode, affine gaps: the walk of kernels_affine.hip's ba_trace_affine_kernel -- over (level, cell),
+// reading the four decision bits -- done by one wavefront over the staged tiles of the linear walk.  On the middle
+// level lane q looks at cell (i-q, j-q) and a run of diagonal moves is one round; on a gap level lane q looks at the
+// q-th cell along the gap and the run ends at the first cell that opened the gap.  Local: the true score V is carried
+// along (the substitution scores of a diagonal run as a prefix sum over the lanes) and the walk ends at the first
+// middle-level cell with V = 0.
+// ----------------------------------------------------------------------------
+
+// affine local: (largest true score, first step) of every row -> first maximum in row-major order -> P.walk
+template <int T>
+__global__ void __launch_bounds__(1024) ba_long_affine_find_kernel(BaLongParams P)
+{
+    __shared__ int red_v[16];
+    __shared__ uint32_t red_k[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t rows = (uint32_t)P.strips * 64u * (uint32_t)T;  // in row order: (strip, lane, r)
+    int best = 0;
+    uint32_t bk = 0xffffffffu;
+    for (uint32_t k = (uint32_t)tid; k < rows; k += 1024u) {
+        const int v = P.lane_max[(size_t)k * 2];
+        if (v > best || (v == best && k < bk)) {
+            best = v;
+            bk = k;
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int ov = __shfl_xor(best, d);
+        const uint32_t ok = (uint32_t)__shfl_xor((int)bk, d);
+        if (ov > best || (ov == best && ok < bk)) {
+            best = ov;
+            bk = ok;
+        }
+    }
+    if (lane == 0) {
+        red_v[wave] = best;
+        red_k[wave] = bk;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        best = red_v[0];
+        bk = red_k[0];
+        for (int q = 1; q < 16; ++q)
+            if (red_v[q] > best || (red_v[q] == best && red_k[q] < bk)) {
+                best = red_v[q];
+                bk = red_k[q];
+            }
+        int fi = 0, fj = 0;
+        if (best > 0) {
+            const int RS = 64 * T;
+            const int s = (int)(bk / (uint32_t)RS), rem = (int)(bk % (uint32_t)RS), l = rem / T;
+            const int step = P.lane_max[(size_t)bk * 2 + 1];
+            fi = (int)P.n - ((int)P.strips - s) * RS + rem + 1;
+            fj = step - l + 1;
+        }
+        *P.score = (int64_t)best;
+        P.walk[0] = (uint32_t)fi;
+        P.walk[1] = (uint32_t)fj;
+        P.walk[2] = 0;
+        P.walk[3] = (uint32_t)best;
+        P.walk[4] = (uint32_t)fi;
+        P.walk[5] = (uint32_t)fj;
+    }
+}
+
+template <int MODE, int T>
+__global__ void __launch_bounds__(64) ba_long_walk_affine_kernel(BaLongParams P)
+{
+    using G = BaLongGeom<T, 4>;
+    constexpr int RS = G::RS, CPD = G::CPD;
+    __shared__ uint32_t tile[64 * 64];
+    __shared__ uint32_t above[64];
+    const int lane = threadIdx.x;
+    const int n = (int)P.n, m = (int)P.m;
+    const int go = P.gap, ge = P.gap_ext, cc = go - ge;
+    const int strips = (int)P.strips;
+    const int front = strips * RS - n;
+    const int wps = (int)P.words_per_strip;
+    constexpr bool top_free = (MODE == BA_LOCAL || MODE == BA_FITTING);
+    constexpr bool left_free = (MODE == BA_LOCAL || MODE == BA_OVERLAP);
+    const int32_t *bottom_row = P.bnd + (size_t)(P.nsuper - 1) * P.bnd_stride * 2;  // granules: low dword = hq(n, j)
+
+    // end cell: global (n, m) (align_pair.go:123-126); fitting / overlap the leftmost strict maximum of the bottom row's
+    // true scores, from column 0 (align_pair.go:169-182); local: ba_long_affine_find_kernel has found it
+    int i = n, j = m, V = 0;
+    if (MODE == BA_LOCAL) {
+        i = (int)P.walk[0];
+        j = (int)P.walk[1];
+        V = (int)P.walk[3];
+    } else if (MODE == BA_GLOBAL) {
+        V = bottom_row[2 * (m - 1)] + cc - ge * (n + m);
+    } else {
+        // H'(n, j) - ext*j orders the bottom row as the true scores do
+        const int col0n = left_free ? ge * n : -cc;  // H'(n, 0), n >= 1
+        int bj = 0, bv = col0n - cc;
+        for (int c0 = 0; c0 < m; c0 += 64) {
+            const int col = c0 + lane;
+            int v = col < m ? bottom_row[2 * col] - ge * (col + 1) : INT32_MIN;
+            int jj = col + 1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int ov = __shfl_xor(v, d), oj = __shfl_xor(jj, d);
+                if (ov > v || (ov == v && oj < jj)) {
+                    v = ov;
+                    jj = oj;
+                }
+            }
+            if (v > bv) {
+                bv = v;
+                bj = jj;
+            }
+        }
+        j = bj;
+        V = bv + cc - ge * n;
+    }
+    i = __builtin_amdgcn_readfirstlane(i);
+    j = __builtin_amdgcn_readfirstlane(j);
+    V = __builtin_amdgcn_readfirstlane(V);
+    if (lane == 0) {
+        if (MODE != BA_LOCAL) *P.score = (int64_t)V;
+        P.walk[0] = (uint32_t)i;
+        P.walk[1] = (uint32_t)j;
+        P.walk[2] = 0;
+        P.walk[3] = (uint32_t)V;
+        P.walk[4] = (uint32_t)i;
+        P.walk[5] = (uint32_t)j;
+    }
+    if (P.score_only) return;
+
+    // staged decision words (the tiles of ba_long_walk_kernel)
+    int tile_s = -1, tile_u = 0, ab_s = -1, ab_u = 0;
+    auto load_tile = [&](int s, int u) {
+        tile_s = s;
+        tile_u = max(0, min(u - 55, wps - 64));
+        const uint32_t *src = P.resid + ((size_t)s * wps + tile_u) * 64;
+        const int words = min(64, wps - tile_u);
+        uint32_t v[64];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) v[q] = src[(size_t)min(q, words - 1) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) tile[q * 64 + lane] = v[q];
+    };
+    auto load_above = [&](int s, int u) {
+        ab_s = s;
+        ab_u = max(0, min(u - 55, wps - 64));
+        const int uu = ab_u + lane;
+        above[lane] = uu < wps ? P.resid[((size_t)s * wps + uu) * 64 + 63] : 0u;
+    };
+    // stages what cell (ii, jj) needs, 1 <= ii <= n, 1 <= jj <= m (uniform)
+    auto stage = [&](int ii, int jj) {
+        const int tt = ii - 1 + front;
+        const int s = tt / RS, l = (tt % RS) / T;
+        const int u = ((jj - 1) + l) / CPD;
+        if (s == tile_s || tile_s < 0 || l != 63) {
+            if (s != tile_s || u < tile_u || u >= tile_u + 64) load_tile(s, u);
+        } else if (s != ab_s || u < ab_u || u >= ab_u + 64) {
+            load_above(s, u);
+        }
+    };
+    // the four bits of cell (ii, jj) if they are staged (per lane): bit 3 nF, bit 2 nD, bit 1 oE, bit 0 oF
+    auto peek = [&](int ii, int jj, bool &ok) -> uint32_t {
+        const int tt = ii - 1 + front;
+        const int s = tt / RS, l = (tt % RS) / T, r = tt % T;
+        const int t = (jj - 1) + l;
+        const int u = t / CPD;
+        const uint32_t sh = (uint32_t)(((t % CPD) * T + r) * 4);
+        uint32_t word = 0;
+        if (s == tile_s || l != 63) {
+            const bool in = (s == tile_s) && u >= tile_u && u < tile_u + 64;
+            ok = ok && in;
+            word = tile[(in ? (u - tile_u) : 0) * 64 + l];
+        } else {
+            const bool in = (s == ab_s) && u >= ab_u && u < ab_u + 64;
+            ok = ok && in;
+            word = above[in ? (u - ab_u) : 0];
+        }
+        return (word >> sh) & 15u;
+    };
+
+    uint32_t *ops = P.ops;
+    uint64_t opacc = 0;
+    uint32_t fill = 0, k = 0;
+    auto emit_run = [&](uint32_t mv, uint32_t count) {
+        const uint64_t pattern = mv == BA_MV_DIAG ? 0xAAAAAAAAAAAAAAAAull : mv == BA_MV_LEFT ? 0x5555555555555555ull : 0ull;
+        while (count > 0) {
+            const uint32_t c = min(count, 32u - fill);
+            const uint64_t bits = c == 32 ? pattern : (pattern & ((1ull << (2 * c)) - 1ull));
+            opacc |= bits << (2 * fill);
+            fill += c;
+            count -= c;
+            if (fill == 32) {
+                if (lane == 0) {
+                    ops[k >> 4] = (uint32_t)opacc;
+                    ops[(k >> 4) + 1] = (uint32_t)(opacc >> 32);
+                }
+                k += 32;
+                opacc = 0;
+                fill = 0;
+            }
+        }
+    };
+
+    enum { LV_MM = 0, LV_G1 = 1, LV_G2 = 2 };
+    int level = LV_MM;
+    // every round stages a tile or moves: a walk that is still going after this many rounds has lost its way (cannot
+    // happen with decision bits the DP wrote; the status word makes the host report it)
+    int64_t rounds_left = 4 * ((int64_t)n + m) + 1024;
+    if (i < 0 || i > n || j < 0 || j > m) rounds_left = 0;
+    while (!(level == LV_MM && i == 0 && j == 0)) {
+        if (--rounds_left < 0) {
+            if (lane == 0) atomicAdd(P.status, 1u);
+            break;
+        }
+        if (level == LV_MM) {
+            if (i == 0) {  // top border: sg2 = -inf, no diagonal
+                if (top_free || j == 0) break;
+                level = LV_G1;
+                continue;
+            }
+            if (j == 0) {  // left border
+                if (left_free) break;
+                level = LV_G2;
+                continue;
+            }
+            if (MODE == BA_LOCAL && V == 0) break;  // skip-prefix cell
+            const int ii = i - lane, jj = j - lane;
+            bool ok = ii >= 1 && jj >= 1;
+            uint32_t nib = 0;
+            if (ok) nib = peek(ii, jj, ok);
+            const uint64_t okmask = __ballot(ok);
+            if (!(okmask & 1ull)) {
+                stage(i, j);
+                continue;
+            }
+            const bool is_diag = ok && (nib & 8u) && !(nib & 4u);  // not from F, diagonal candidate equals H
+            const uint64_t dmask = __ballot(is_diag);
+            const uint32_t run = dmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~dmask);
+            if (MODE == BA_LOCAL) {
+                // true scores along the run: V drops by the substitution score of every diagonal move
+                int wq = 0;
+                if (ok) wq = P.table[(int)P.code1[P.s1[ii - 1]] * P.nb + (int)P.code2[P.s2[jj - 1]]];
+                int incl = wq;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int a = __shfl_up(incl, d);
+                    if (lane >= d) incl += a;
+                }
+                const int vq = V - (incl - wq);  // true score of my cell while every lane below me moves diagonally
+                const uint64_t zmask = __ballot(ok && vq == 0);
+                const uint32_t stop = zmask ? (uint32_t)__builtin_ctzll(zmask) : 64u;
+                if (zmask && stop <= run) {
+                    emit_run(BA_MV_DIAG, stop);
+                    i -= (int)stop;
+                    j -= (int)stop;
+                    break;
+                }
+                if (run > 0) V -= __builtin_amdgcn_readlane(incl, (int)run - 1);
+            }
+            emit_run(BA_MV_DIAG, run);
+            i -= (int)run;
+            j -= (int)run;
+            if (run < 64 && ((okmask >> run) & 1ull)) {
+                // lane `run` sits on the cell the run ends at: closing a gap in s2 comes first, then the diagonal (taken
+                // above), then a gap in s1 (align_affine.go:82-100)
+                const uint32_t nb_ = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)run);
+                level = (nb_ & 8u) ? LV_G1 : LV_G2;
+            }
+        } else if (level == LV_G1) {
+            // gap in s1: (gap, s2[j-1]) per move, j >= 1; the gap was opened at column 1, on the top border only there,
+            // else where the oE bit says so
+            const int jj = j - lane;
+            bool ok = jj >= 1;
+            bool opened = false;
+            if (ok) {
+                if (jj == 1) opened = true;
+                else if (i > 0) opened = (peek(i, jj, ok) & 2u) != 0;
+            }
+            const uint64_t okmask = __ballot(ok);
+            if (!(okmask & 1ull)) {
+                stage(i, j);
+                continue;
+            }
+            const uint32_t usable = okmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okmask);  // staged prefix
+            const uint64_t omask = __ballot(ok && opened) & (usable == 64 ? ~0ull : ((1ull << usable) - 1ull));
+            if (omask) {
+                const uint32_t first = (uint32_t)__builtin_ctzll(omask);
+                emit_run(BA_MV_LEFT, first + 1);
+                j -= (int)first + 1;
+                if (MODE == BA_LOCAL) V += (int)first * ge + go;
+                level = LV_MM;
+            } else {
+                emit_run(BA_MV_LEFT, usable);
+                j -= (int)usable;
+                if (MODE == BA_LOCAL) V += (int)usable * ge;
+            }
+        } else {
+            // gap in s2: (s1[i-1], gap) per move, i >= 1
+            const int ii = i - lane;
+            bool ok = ii >= 1;
+            bool opened = false;
+            if (ok) {
+                if (ii == 1) opened = true;
+                else if (j > 0) opened = (peek(ii, j, ok) & 1u) != 0;
+            }
+            const uint64_t okmask = __ballot(ok);
+            if (!(okmask & 1ull)) {
+                stage(i, j);
+                continue;
+            }
+            const uint32_t usable = okmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okmask);
+            const uint64_t omask = __ballot(ok && opened) & (usable == 64 ? ~0ull : ((1ull << usable) - 1ull));
+            if (omask) {
+                const uint32_t first = (uint32_t)__builtin_ctzll(omask);
+                emit_run(BA_MV_UP, first + 1);
+                i -= (int)first + 1;
+                if (MODE == BA_LOCAL) V += (int)first * ge + go;
+                level = LV_MM;
+            } else {
+                emit_run(BA_MV_UP, usable);
+                i -= (int)usable;
+                if (MODE == BA_LOCAL) V += (int)usable * ge;
+            }
+        }
+    }
+    if (lane == 0) {
+        if (fill > 0) ops[k >> 4] = (uint32_t)opacc;
+        if (fill > 16) ops[(k >> 4) + 1] = (uint32_t)(opacc >> 32);
+        P.walk[2] = k + fill;
+        P.walk[4] = (uint32_t)i;
+        P.walk[5] = (uint32_t)j;
+    }
+}
+
 __global__ void __launch_bounds__(1024) ba_long_expand_kernel(BaLongParams P)
 {
     __shared__ uint32_t wsum1[16], wsum2[16];
@@ -1003,16 +1476,16 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
         if constexpr (MODE == BA_LOCAL) {
             return hipErrorInvalidValue;  // (local mode runs unstriped)
         } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K, true, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
-            hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K, true>), dim3(P.wg_count), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+            hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K, true, false>), dim3(P.wg_count), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
     } else if (phases & BA_LONG_PHASE_DP) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K, false, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
         const uint32_t wgs = P.wg_count ? P.wg_count : P.nsuper - P.wg_begin;
-        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K, false>), dim3(wgs), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K, false, false>), dim3(wgs), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (phases & BA_LONG_PHASE_WALK) {
@@ -1040,6 +1513,64 @@ static hipError_t launch_long_mode(const BaLongParams &P, int T, int K, int phas
     if (T == 4 && K == 2) return launch_long<MODE, 4, 2>(P, phases, st);
     if (T == 4 && K == 4) return launch_long<MODE, 4, 4>(P, phases, st);
     if (T == 4 && K == 8) return launch_long<MODE, 4, 8>(P, phases, st);
+    return hipErrorInvalidValue;
+}
+
+// affine gaps: DP (K = 4: four decision bits per cell), then (local) the best-cell search, the walk and the expansion
+template <int MODE, int T>
+static hipError_t launch_long_affine(const BaLongParams &P, int phases, hipStream_t st)
+{
+    // two hand-over rings per strip (hq and F') are 80 KB of static LDS: the padding that keeps a CU to one workgroup
+    // shrinks accordingly
+    const size_t prof_lds = (size_t)BA_LONG_W * (size_t)P.nb * 256;
+    const size_t pad_lds = std::max<size_t>(prof_lds, 44 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, 4, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
+    if (e != hipSuccess) return e;
+    if (phases & BA_LONG_PHASE_DP) {
+        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, 4, false, true>), dim3(P.nsuper), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (phases & BA_LONG_PHASE_WALK) {
+        if constexpr (MODE == BA_LOCAL) {
+            hipLaunchKernelGGL((ba_long_affine_find_kernel<T>), dim3(1), dim3(1024), 0, st, P);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((ba_long_walk_affine_kernel<MODE, T>), dim3(1), dim3(64), 0, st, P);
+        if ((e = hipGetLastError()) != hipSuccess || P.score_only) return e;
+        hipLaunchKernelGGL(ba_long_expand_kernel, dim3(1), dim3(1024), 0, st, P);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+template <int MODE>
+static hipError_t launch_long_affine_mode(const BaLongParams &P, int T, int phases, hipStream_t st)
+{
+    if (T == 2) return launch_long_affine<MODE, 2>(P, phases, st);
+    if (T == 4) return launch_long_affine<MODE, 4>(P, phases, st);
+    return hipErrorInvalidValue;
+}
+
+// affine: rows per lane.  A row's step is a chain of three dependent operations (max, max3, subtract) instead of one:
+// shorter strips than the linear kernel's.  BIOALIGN_LONG_AFFINE_T=4 for experiments.
+extern "C" int ba_long_affine_rows_per_lane(void)
+{
+    const char *e = getenv("BIOALIGN_LONG_AFFINE_T");
+    return (e && atoi(e) == 4) ? 4 : 2;
+}
+
+extern "C" hipError_t ba_launch_long_affine(const BaLongParams &P, int mode, int T, int phases, hipStream_t st)
+{
+    if (P.n == 0 || P.m == 0 || P.strips == 0 || (uint64_t)P.nsuper * BA_LONG_W < P.strips) return hipErrorInvalidValue;
+    if (P.multi || P.left_col || P.right_col || P.col0 || P.wg_begin || P.wg_count) return hipErrorInvalidValue;  // unstriped only
+    if (P.gap < P.gap_ext || P.gap_ext < 0 || P.epoch == 0 || P.epoch >= 0x800000u) return hipErrorInvalidValue;
+    switch (mode) {
+    case BA_GLOBAL: return launch_long_affine_mode<BA_GLOBAL>(P, T, phases, st);
+    case BA_LOCAL: return P.lane_max ? launch_long_affine_mode<BA_LOCAL>(P, T, phases, st) : hipErrorInvalidValue;
+    case BA_FITTING: return launch_long_affine_mode<BA_FITTING>(P, T, phases, st);
+    case BA_OVERLAP: return launch_long_affine_mode<BA_OVERLAP>(P, T, phases, st);
+    }
     return hipErrorInvalidValue;
 }
 

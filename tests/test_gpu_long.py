@@ -93,14 +93,76 @@ def test_long_several_strips_and_align_global_ls():
 
 
 def test_long_unsupported_fails_loudly():
-    # affine gaps are the batch kernels' (bioalign_batch); long mode says so instead of computing something else
-    from bio_amd import _native, pack_sequences, score_table
-    d1, o1 = pack_sequences([b"ACGT" * 10]); d2, o2 = pack_sequences([b"ACG" * 10])
-    tbl, c1, c2 = score_table(bio_amd.MatchAligner(1, -1), np.unique(d1).tolist(), np.unique(d2).tolist())
-    pb = _native.PackedBatch(d1, o1, d2, o2, "global", tbl, c1, c2, gap_open=5, gap_extend=1)
-    with pytest.raises(_native.BioAlignError) as e:
-        bio_amd.align.engine().batch(pb, long=True)
-    assert e.value.code == _native.EUNSUPPORTED
+    # what the long kernels do not cover is refused, not computed some other way: more than 64 column symbols, and
+    # gap penalties with open < extend
+    x = bytes(range(40, 140)) * 3
+    with pytest.raises(bio_amd._native.BioAlignError) as e:
+        bio_amd.AlignPairLong("global", x, x[::-1], bio_amd.MatchAligner(1, -1), 1)
+    assert e.value.code == bio_amd._native.EUNSUPPORTED
+    with pytest.raises(bio_amd._native.BioAlignError) as e:
+        bio_amd.AlignAffinePairLong("global", b"ACGT" * 10, b"ACG" * 10, bio_amd.MatchAligner(1, -1), 1, 3)
+    assert e.value.code == bio_amd._native.EUNSUPPORTED
+
+
+def _affine_same(mode, x, y, a, oa, go, ge):
+    got = bio_amd.AlignAffinePairLong(mode, x, y, a, go, ge)
+    want = O.AlignAffine(mode, x, y, oa, go, ge)
+    assert got == want, (mode, len(x), len(y), go, ge, got[0], want[0])
+
+
+@pytest.mark.parametrize("mode", MODES4)
+def test_long_affine_small_shapes(mode):
+    # Gotoh's three levels (align_affine.go:44-103) on the long-mode mapping, against the oracle's bo_align_affine
+    a, oa = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
+    shapes = [(1, 1), (5, 7), (7, 5), (63, 64), (64, 63), (65, 65), (100, 127), (128, 128), (130, 129), (255, 70),
+              (256, 200), (257, 190), (700, 900), (1100, 300), (30, 1000), (600, 3)]
+    for k, (n, m) in enumerate(shapes):
+        x, y = _pair(n, m, 900 + k)
+        _affine_same(mode, x, y, a, oa, 5, 1)
+
+
+@pytest.mark.parametrize("gaps", [(5, 1), (3, 0), (2, 2 - 1), (11, 1), (4, 3)])
+def test_long_affine_penalties_and_gap_heavy_pairs(gaps):
+    go, ge = gaps
+    a, oa = bio_amd.MatchAligner(2, -3), O.MatchAligner(2, -3)
+    rng = random.Random(go * 10 + ge)
+    for _ in range(3):
+        # long insertions and deletions: gap runs that cross lanes and strips
+        core = bytes(rng.choice(b"ACGT") for _ in range(700))
+        x = core[:200] + bytes(rng.choice(b"ACGT") for _ in range(rng.randrange(1, 300))) + core[200:]
+        y = core[:450] + core[450 + rng.randrange(1, 200):]
+        for mode in MODES4:
+            _affine_same(mode, x, y, a, oa, go, ge)
+            _affine_same(mode, y, x, a, oa, go, ge)
+
+
+def test_long_affine_protein_and_low_complexity():
+    s1, o1, s2, o2 = synth.protein_pairs(1, 1500, 1700, config=3, first=11)
+    x, y = s1.tobytes(), s2.tobytes()
+    for mode in MODES4:
+        _affine_same(mode, x, y, bio_amd.Blosum62, O.Blosum62(), 11, 1)
+    rng = random.Random(17)
+    a, oa = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
+    for _ in range(3):
+        x = bytes(rng.choice(b"AAAC") for _ in range(rng.randrange(300, 900)))
+        y = bytes(rng.choice(b"AAAC") for _ in range(rng.randrange(300, 900)))
+        for mode in MODES4:
+            _affine_same(mode, x, y, a, oa, 3, 1)
+    # nothing matches: local scores 0 with empty traces, global is one long gap pair
+    for mode in MODES4:
+        _affine_same(mode, b"A" * 300, b"C" * 200, a, oa, 4, 1)
+
+
+def test_long_affine_3000_blosum62_and_align_global_affine():
+    s1, o1, s2, o2 = synth.protein_pairs(1, 3100, 3300, config=3, first=7)
+    x, y = s1.tobytes(), s2.tobytes()
+    for mode in ("global", "local"):
+        _affine_same(mode, x, y, bio_amd.Blosum62, O.Blosum62(), 11, 1)
+    # AlignGlobalAffine (align_affine.go:12) routes pairs of >= 2^24 cells to the long kernels: score as written
+    x, y = _pair(4200, 4100, 77)
+    sc, t1, t2 = bio_amd.AlignGlobalAffine(x, y, bio_amd.MatchAligner(1, -1), 5.0, 1.0)
+    assert sc == O.AffineGlobalScoreF64(x, y, O.MatchAligner(1, -1), 5.0, 1.0)
+    assert (int(sc), t1, t2) == O.AlignAffine("global", x, y, O.MatchAligner(1, -1), 5, 1)
 
 
 @pytest.mark.parametrize("mode", MODES4)
