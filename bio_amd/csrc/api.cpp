@@ -1207,12 +1207,36 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     HIP_TRY(ctx, hipSetDevice(ctx->devices[0]));
     DevBuf d_s1, d_s2, d_prof, d_c1, d_c2, d_tab, d_bnd, d_res, d_misc, d_t1, d_t2, d_ops, d_lmax;
     int rc;
+    // Residue words: strips * wps * 256 bytes (K bits per cell).  Score only: none are stored.  A matrix whose residues
+    // exceed the budget (BIOALIGN_LONG_RESIDUE_BYTES; default 70 % of the device's free memory) is traced back in
+    // LINEAR SPACE (north_star's Hirschberg item): the DP runs once without storing residues -- every
+    // workgroup's bottom row stays in HBM as a checkpoint -- and then row blocks of workgroups are recomputed bottom-up
+    // with residues, each from the checkpoint above it and only as far right as the walk has come, and walked at
+    // once.  At most twice the cells, the traces the same as with the whole matrix (the walk is the same walk).
+    // Linear gaps, global / fitting / overlap.
+    const uint64_t resid_all = strips * wps * 256;
+    uint64_t budget = env_u64("BIOALIGN_LONG_RESIDUE_BYTES", 0);
+    if (budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        budget = (uint64_t)(0.7 * (double)free_b);
+    }
+    const bool checkpointed = traces && resid_all > budget;
+    if (checkpointed && (affine || in->mode == BIOALIGN_LOCAL))
+        return ctx->fail(BIOALIGN_ENOMEM, "long mode: %llu bytes of traceback matrix do not fit %llu (the linear-space traceback "
+                         "covers linear gaps in global, fitting and overlap mode)", (unsigned long long)resid_all, (unsigned long long)budget);
+    const uint64_t W_ = (uint64_t)ba_long_strips_per_group();
+    // workgroups per recomputed block: as many as the budget holds (at least one)
+    const uint64_t wgs_per_block = checkpointed ? std::max<uint64_t>(1, budget / (W_ * wps * 256)) : nsuper;
+    // (score only, linear gaps, not local: nothing reads residues, none are stored)
+    const bool no_resid = !traces && !affine && in->mode != BIOALIGN_LOCAL;
+    const uint64_t resid_bytes = no_resid ? 0 : checkpointed ? std::min(nsuper, wgs_per_block) * W_ * wps * 256 : resid_all;
     // local: per lane its largest score (affine: per row its largest true score and the step it was reached at)
     if (in->mode == BIOALIGN_LOCAL && (rc = d_lmax.alloc(ctx, strips * 64 * 4 * (affine ? 2 * (size_t)T : 1)))) return rc;
     if ((rc = d_s1.alloc(ctx, n + 16)) || (rc = d_s2.alloc(ctx, m + 16)) || (rc = d_prof.alloc(ctx, rowprof.size() * 4)) ||
         (rc = d_c1.alloc(ctx, 256)) || (rc = d_c2.alloc(ctx, 256)) || (rc = d_tab.alloc(ctx, (size_t)in->na * in->nb * 4)) ||
         (rc = d_bnd.alloc(ctx, nsuper * ((m + 15) / 16 * 16) * 8 + 256)) ||
-        (rc = d_res.alloc(ctx, strips * wps * 256)) || (rc = d_misc.alloc(ctx, 64)))
+        (rc = d_res.alloc(ctx, resid_bytes)) || (rc = d_misc.alloc(ctx, 64)))
         return rc;
     const uint64_t cap = n + m;
     if (traces && ((rc = d_t1.alloc(ctx, cap + 32)) || (rc = d_t2.alloc(ctx, cap + 32)) ||
@@ -1267,16 +1291,65 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     P.start_i = 0;
     P.start_j = -1;
     P.scan_only = 0;
+    P.no_resid = no_resid ? 1 : 0;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(ctx, hipEventCreate(&e0));
     HIP_TRY(ctx, hipEventCreate(&e1));
     HIP_TRY(ctx, hipEventRecord(e0, st));
-    hipError_t le = affine ? ba_launch_long_affine(P, in->mode, T, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK, st)
-                           : ba_launch_long(P, in->mode, T, K, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK, st);
-    if (le == hipSuccess) le = hipEventRecord(e1, st);
+    hipError_t le = hipSuccess;
     uint64_t misc[8] = {0};
-    if (le == hipSuccess) le = hipMemcpyAsync(misc, d_misc.p, 64, hipMemcpyDeviceToHost, st);
+    if (!checkpointed) {
+        le = affine ? ba_launch_long_affine(P, in->mode, T, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK, st)
+                    : ba_launch_long(P, in->mode, T, K, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK, st);
+    } else {
+        // pass 1: scores only, then the end cell (the walk kernel's scan of the last workgroup's bottom row)
+        BaLongParams P1 = P;
+        P1.no_resid = 1;
+        P1.scan_only = 1;
+        le = ba_launch_long(P1, in->mode, T, K, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK, st);
+        if (le == hipSuccess) le = hipMemcpyAsync(misc, d_misc.p, 64, hipMemcpyDeviceToHost, st);
+        if (le == hipSuccess) le = hipStreamSynchronize(st);
+        const uint32_t *mw = reinterpret_cast<const uint32_t *>(misc);
+        uint64_t ci = mw[8 + 0], cj = mw[8 + 1], done = 0;  // the cell the walk is in; moves expanded so far
+        const int64_t score_seen = (int64_t)misc[1];
+        const uint64_t padw = nsuper * W_ - strips;
+        // pass 2: row blocks bottom-up
+        for (uint64_t hi = nsuper; le == hipSuccess && mw[0] == 0 && ci > 0 && cj > 0 && hi > 0;) {
+            const uint64_t lo = hi > wgs_per_block ? hi - wgs_per_block : 0;
+            const int64_t s_first = std::max<int64_t>((int64_t)(lo * W_) - (int64_t)padw, 0);
+            const int64_t stop_row = lo == 0 ? 0 : (int64_t)n - (int64_t)(strips - (uint64_t)s_first) * (int64_t)rs;
+            if ((int64_t)ci <= stop_row) {  // (the walk has left this block's rows already: cannot happen, blocks are contiguous)
+                hi = lo;
+                continue;
+            }
+            BaLongParams Pb = P;
+            Pb.m = (uint32_t)cj;  // nothing right of the walk's column is needed again
+            Pb.words_per_strip = (uint32_t)((cj + 63 + cpd - 1) / cpd);
+            Pb.wg_begin = (uint32_t)lo;
+            Pb.wg_count = (uint32_t)(hi - lo);
+            Pb.first_strip = (int)s_first;
+            Pb.stop_row = (int)stop_row;
+            Pb.start_i = (int)ci;
+            Pb.start_j = (int)cj;
+            Pb.trace_done = (uint32_t)done;
+            Pb.trace_cap = cap;
+            le = ba_launch_long(Pb, in->mode, T, K, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK, st);
+            if (le == hipSuccess) le = hipMemcpyAsync(misc, d_misc.p, 64, hipMemcpyDeviceToHost, st);
+            if (le == hipSuccess) le = hipStreamSynchronize(st);
+            done += mw[8 + 2];
+            ci = mw[8 + 4];
+            cj = mw[8 + 5];
+            hi = lo;
+        }
+        misc[1] = (uint64_t)score_seen;  // (the blocks' walks start from a given cell and leave the score alone)
+        if (le == hipSuccess && done == 0) {  // a walk of no moves (cannot happen for n, m >= 1 in these modes)
+            misc[2] = cap;
+            misc[3] = 0;
+        }
+    }
+    if (le == hipSuccess) le = hipEventRecord(e1, st);
+    if (le == hipSuccess && !checkpointed) le = hipMemcpyAsync(misc, d_misc.p, 64, hipMemcpyDeviceToHost, st);
     if (le == hipSuccess) le = hipStreamSynchronize(st);
     float ms = 0.f;
     if (le == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);

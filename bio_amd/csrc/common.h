@@ -139,6 +139,15 @@ struct BaLongParams {
     int32_t *right_col;            // [n + 1] out: Hs(i, col0 + m) (null: not wanted)
     int start_i, start_j;          // walk: start from this cell instead of looking for the end cell (start_j < 0: look for it)
     int scan_only;                 // walk: find the end cell of this stripe's bottom row, report it, stop
+    // linear-space traceback (checkpointed): the DP runs once without storing residues (no_resid; every workgroup's
+    // bottom row stays in bnd), then row blocks of workgroups are recomputed bottom-up WITH residues (wg_begin /
+    // wg_count, resid = the block's own buffer) and walked one after the other
+    int no_resid;                  // DP: do not store residue words
+    int first_strip;               // walk: strips below this index are not in resid (resid[0] is strip first_strip); the
+                                   // row just above the block is read from bnd row wg_begin - 1
+    int stop_row;                  // walk: stop on reaching this row (the last row above the block; 0: the matrix' top)
+    uint32_t trace_done;           // expansion: moves already expanded by the blocks below (they lie behind this block's)
+    uint64_t trace_cap;            // expansion: capacity of t1 / t2 (0: n + m; a recomputed block runs with a smaller m)
     // several stripes of one pair in ONE launch (all on this device): workgroup b of the grid is workgroup order[b].y of
     // stripe order[b].x and takes its parameters from multi[order[b].x].  A stripe's last column goes to its right
     // neighbour as tagged granules {score, tag} (right_gran, [n + 1], zeroed before the launch); the neighbour's strips

@@ -200,7 +200,8 @@ __device__ __forceinline__ void ba_long_step_aff(int (&hq)[T], int (&e)[T], uint
 // AFF: affine gaps (ba_long_step_aff): a hand-over carries two values per column, hq and F' -- a second LDS ring, and
 // in the HBM granule F' travels as an 8-bit offset from hq (F' <= hq + c always; anything below hq behaves like hq - 1),
 // next to a 24-bit tag.
-template <int MODE, int T, int K, bool MULTI, bool AFF>
+// NORES: no residue words are stored (score only; the first pass of the linear-space traceback).
+template <int MODE, int T, int K, bool MULTI, bool AFF, bool NORES = false>
 __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLongParams P0)
 {
     static_assert(!AFF || (K == 4 && !MULTI), "affine: four decision bits per cell, unstriped");
@@ -426,7 +427,9 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
             prof[b * 64] = word;
         }
     }
-    uint32_t *resid = P.resid + (size_t)s * P.words_per_strip * 64 + lane;
+    // (checkpointed runs: the first pass stores no residues; a row block's pass stores them in the block's own buffer)
+    constexpr bool store_resid = !NORES;
+    uint32_t *resid = P.resid + ((ptrdiff_t)s - (ptrdiff_t)P.first_strip) * (ptrdiff_t)P.words_per_strip * 64 + lane;
 
     // skew state: `bottom` = my last row after the previous step; the lane below me reads it
     int bottom = h[T - 1];
@@ -523,7 +526,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
                             bottom_f = fout;
                             ba_lds_store((j * 16 + k == 63) ? wp63 : wp + j * 16 + k, bottom);
                             ba_lds_store((j * 16 + k == 63) ? wpf63 : wpf + j * 16 + k, bottom_f);
-                            if ((k + 1) % CPD == 0) resid_blk[(size_t)((j * 16 + k) / CPD) * 64] = acc;
+                            if ((k + 1) % CPD == 0 && store_resid) resid_blk[(size_t)((j * 16 + k) / CPD) * 64] = acc;
                         }
                     }
                 };
@@ -539,7 +542,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
                     topprev = top;
                     bottom = h[T - 1];
                     ba_lds_store((j * 16 + k == 63) ? wp63 : wp + j * 16 + k, bottom);
-                    if ((k + 1) % CPD == 0) resid_blk[(size_t)((j * 16 + k) / CPD) * 64] = acc;
+                    if ((k + 1) % CPD == 0 && store_resid) resid_blk[(size_t)((j * 16 + k) / CPD) * 64] = acc;
                 }
             } else {
 #pragma unroll
@@ -552,7 +555,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
                         topprev = top;
                         bottom = h[T - 1];
                         ba_lds_store((j * 16 + k == 63) ? wp63 : wp + j * 16 + k, bottom);
-                        if ((k + 1) % CPD == 0) resid_blk[(size_t)((j * 16 + k) / CPD) * 64] = acc;
+                        if ((k + 1) % CPD == 0 && store_resid) resid_blk[(size_t)((j * 16 + k) / CPD) * 64] = acc;
                     }
                 }
             }
@@ -599,7 +602,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
         }
     }
     // last, partial residue word: its pushes sit at the top, bring them down to their places
-    if (total_steps % CPD != 0)
+    if (total_steps % CPD != 0 && store_resid)
         resid[(size_t)(total_steps / CPD) * 64] = acc >> ((CPD - total_steps % CPD) * T * K);
     // every column is final now
     const bool failed = ld(&fail_s) != 0;
@@ -788,7 +791,8 @@ __global__ void __launch_bounds__(1024) ba_long_local_find_kernel(BaLongParams P
     }
 }
 
-template <int MODE, int T, int K>
+// CKPT: the walk of one recomputed row block of the linear-space traceback (first_strip, stop_row).
+template <int MODE, int T, int K, bool CKPT = false>
 __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
 {
     using G = BaLongGeom<T, K>;
@@ -814,6 +818,10 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
     const int col0 = (int)P.col0;
     const int32_t *left_col = P.left_col;
     const bool first_stripe = (left_col == nullptr);
+    // checkpointed runs: resid holds the strips from first_strip on; the walk stops at stop_row, the last row above them,
+    // whose scores (hence residues) lie in the bottom row of the workgroup above the block
+    const int first_strip = CKPT ? P.first_strip : 0, stop_row = CKPT ? P.stop_row : 0;
+    const int32_t *row_above = P.bnd + (size_t)(P.wg_begin > 0 ? P.wg_begin - 1 : 0) * P.bnd_stride * 2;
 
     // end cell (align.go:123-124; align_pair.go:169-182): n >= 1 and m >= 1 here
     int i = n, j = m, cur = 0, bv = 0;
@@ -879,7 +887,7 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
     auto load_tile = [&](int s, int u) {
         tile_s = s;
         tile_u = max(0, min(u - 55, wps - 64));  // the walk moves towards smaller words
-        const uint32_t *src = P.resid + ((size_t)s * wps + tile_u) * 64;
+        const uint32_t *src = P.resid + ((size_t)(s - first_strip) * wps + tile_u) * 64;
         const int words = min(64, wps - tile_u);
         // all 64 loads in flight at once: one memory latency per tile, not eight
         uint32_t v[64];
@@ -892,7 +900,7 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
         ab_s = s;
         ab_u = max(0, min(u - 55, wps - 64));
         const int uu = ab_u + lane;
-        above[lane] = uu < wps ? P.resid[((size_t)s * wps + uu) * 64 + 63] : 0u;
+        above[lane] = uu < wps ? P.resid[((size_t)(s - first_strip) * wps + uu) * 64 + 63] : 0u;
     };
     // residue of cell (ii, jj), 0 <= ii <= n, 0 <= jj <= m
     auto residue = [&](int ii, int jj) -> uint32_t {
@@ -900,6 +908,7 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
         if (jj == 0) return (uint32_t)(left_col ? left_col[ii] : b_left * ii) & MASK;  // Hs(i, 0) = b_left * i
         const int tt = ii - 1 + front;
         const int s = tt / RS, l = (tt % RS) / T, r = tt % T;
+        if (CKPT && s < first_strip) return (uint32_t)row_above[2 * (jj - 1)] & MASK;  // (row stop_row: nothing above it is asked for)
         const int t = (jj - 1) + l;
         const int u = t / CPD;
         const uint32_t sh = (uint32_t)(((t % CPD) * T + r) * K);
@@ -923,6 +932,13 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
         if (jj == 0) return (uint32_t)(left_col ? left_col[ii] : b_left * ii) & MASK;
         const int tt = ii - 1 + front;
         const int s = tt / RS, l = (tt % RS) / T, r = tt % T;
+        if (CKPT && s < first_strip) {
+            if (ii != stop_row) {
+                ok = false;
+                return 0u;
+            }
+            return (uint32_t)row_above[2 * (jj - 1)] & MASK;
+        }
         const int t = (jj - 1) + l;
         const int u = t / CPD;
         const uint32_t sh = (uint32_t)(((t % CPD) * T + r) * K);
@@ -967,9 +983,9 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
 
     // Lane q looks at cell (i - q, j - q): the cells of a diagonal run are evaluated together, and
     // one round of LDS reads advances the walk by the whole run plus the move that ends it.
-    while (i > 0 && j > 0) {
+    while (i > stop_row && j > 0) {
         const int ii = i - lane, jj = j - lane;
-        bool ok = ii >= 1 && jj >= 1;
+        bool ok = ii > stop_row && jj >= 1;
         uint32_t rcq = 0, ruq = 0, rlq = 0, rdq = 0;
         if (ok) {
             rcq = peek(ii, jj, ok);
@@ -1046,7 +1062,7 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
     }
     // borders (align.go:92-100; align_pair.go:110-113, 158-159, 187-188).  A stripe that is not the first one
     // hands the walk on at its column 0 (the left border is not its own); the top border is every stripe's.
-    if (first_stripe && !left_free && i > 0) {
+    if (first_stripe && !left_free && i > 0 && j == 0) {
         emit_run(BA_MV_UP, (uint32_t)i);
         i = 0;
     }
@@ -1402,7 +1418,7 @@ __global__ void __launch_bounds__(1024) ba_long_expand_kernel(BaLongParams P)
     __shared__ uint32_t wsum1[16], wsum2[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t L = P.walk[2];
-    const uint64_t cap = (uint64_t)P.n + (uint64_t)P.m;
+    const uint64_t cap = P.trace_cap ? P.trace_cap : (uint64_t)P.n + (uint64_t)P.m;
     const uint32_t gs = P.gap_symbol;
     uint32_t i0 = P.walk[0], j0 = P.walk[1];  // row / column of the first move of the current round
     for (uint32_t base = 0; base < L; base += 16 * 1024) {
@@ -1442,7 +1458,7 @@ __global__ void __launch_bounds__(1024) ba_long_expand_kernel(BaLongParams P)
         uint32_t ii = i0 - (off1 + p1 - c1), jj = j0 - (off2 + p2 - c2);  // cell of my first move
         for (uint32_t q = 0; q < cnt; ++q) {
             const uint32_t mv = (w >> (2 * q)) & 3u;
-            const uint64_t pos = cap - 1 - (uint64_t)(first + q);
+            const uint64_t pos = cap - 1 - (uint64_t)P.trace_done - (uint64_t)(first + q);
             P.t1[pos] = mv == BA_MV_LEFT ? (uint8_t)gs : P.s1[ii - 1];
             P.t2[pos] = mv == BA_MV_UP ? (uint8_t)gs : P.s2[jj - 1];
             ii -= (mv != BA_MV_LEFT);
@@ -1453,8 +1469,8 @@ __global__ void __launch_bounds__(1024) ba_long_expand_kernel(BaLongParams P)
         __syncthreads();
     }
     if (tid == 0) {
-        *P.t_off = cap - L;
-        *P.t_len = L;
+        *P.t_off = cap - P.trace_done - L;
+        *P.t_len = (uint64_t)P.trace_done + L;
     }
 }
 
@@ -1485,7 +1501,13 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K, false, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
         const uint32_t wgs = P.wg_count ? P.wg_count : P.nsuper - P.wg_begin;
-        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K, false, false>), dim3(wgs), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+        if (P.no_resid) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, K, false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
+            hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K, false, false, true>), dim3(wgs), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+        } else {
+            hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, K, false, false>), dim3(wgs), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (phases & BA_LONG_PHASE_WALK) {
@@ -1493,7 +1515,10 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
             hipLaunchKernelGGL((ba_long_local_find_kernel<T, K>), dim3(1), dim3(1024), 0, st, P);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
-        hipLaunchKernelGGL((ba_long_walk_kernel<MODE, T, K>), dim3(1), dim3(64), 0, st, P);
+        if (P.first_strip || P.stop_row)
+            hipLaunchKernelGGL((ba_long_walk_kernel<MODE, T, K, true>), dim3(1), dim3(64), 0, st, P);
+        else
+            hipLaunchKernelGGL((ba_long_walk_kernel<MODE, T, K>), dim3(1), dim3(64), 0, st, P);
         if ((e = hipGetLastError()) != hipSuccess || P.score_only || P.scan_only) return e;
         hipLaunchKernelGGL(ba_long_expand_kernel, dim3(1), dim3(1024), 0, st, P);
         e = hipGetLastError();

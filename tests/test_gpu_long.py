@@ -241,6 +241,46 @@ def test_long_column_stripes_20k_merged_and_row_blocks(monkeypatch):
     assert (int(sc[0]), t1[a:a + l].tobytes(), t2[a:a + l].tobytes()) == ref  # the unstriped run gives the same traces
 
 
+@pytest.mark.parametrize("budget", ["1", "3000000"])
+def test_long_linear_space_traceback(budget, monkeypatch):
+    # north_star's Hirschberg item (align_linear.go:9-145 is the reference's own linear-space function): when the residue
+    # words do not fit the budget, the DP runs once without them and row blocks are recomputed bottom-up from the
+    # checkpointed rows and walked one after the other -- the same traces as with the whole matrix in memory
+    monkeypatch.setenv("BIOALIGN_LONG_RESIDUE_BYTES", budget)  # 1: one workgroup (1024 rows) per block
+    a, oa = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
+    shapes = [(5, 7), (1024, 300), (1025, 1030), (3000, 2500), (2100, 4000), (4100, 700), (2500, 60)]
+    for k, (n, m) in enumerate(shapes):
+        x, y = _pair(n, m, 1200 + k)
+        for mode in ("global", "fitting", "overlap"):
+            assert bio_amd.AlignPairLong(mode, x, y, a, 1) == O.AlignPair(mode, x, y, oa, 1), (mode, n, m)
+    # walks that run along the borders and leave blocks through column 0
+    rng = random.Random(5)
+    core = bytes(rng.choice(b"ACGT") for _ in range(300))
+    junk = lambda k: bytes(rng.choice(b"ACGT") for _ in range(k))
+    for x, y in [(junk(2500) + core, core + junk(400)), (core + junk(2600), junk(500) + core), (junk(1500) + core + junk(1500), core)]:
+        for mode in ("global", "fitting", "overlap"):
+            assert bio_amd.AlignPairLong(mode, x, y, a, 1) == O.AlignPair(mode, x, y, oa, 1), (mode, len(x), len(y))
+    # what the linear-space traceback does not cover says so
+    with pytest.raises(bio_amd._native.BioAlignError) as e:
+        bio_amd.AlignPairLong("local", junk(5000), junk(5000), a, 1)  # 6.5 MB of residues
+    assert e.value.code == bio_amd._native.ENOMEM
+
+
+def test_long_linear_space_traceback_20k(monkeypatch):
+    from bio_amd import _native
+    s1, o1, s2, o2 = synth.dna_pairs(1, 20_000, 20_000, config=5, sub=0.06, ins=0.02, dele=0.02)
+    table, c1, c2 = synth.dna_table(1, -1)
+    eng = bio_amd.align.engine()
+    pb = _native.PackedBatch(s1, o1, s2, o2, "global", table, c1, c2, 1, 1)
+    sc, t1, t2, toff, tlen = eng.long(pb)
+    a, l = int(toff[0]), int(tlen[0])
+    ref = (int(sc[0]), t1[a:a + l].tobytes(), t2[a:a + l].tobytes())
+    monkeypatch.setenv("BIOALIGN_LONG_RESIDUE_BYTES", str(30_000_000))  # the whole matrix needs 100 MB: four blocks
+    sc, t1, t2, toff, tlen = eng.long(pb)
+    a, l = int(toff[0]), int(tlen[0])
+    assert (int(sc[0]), t1[a:a + l].tobytes(), t2[a:a + l].tobytes()) == ref
+
+
 def test_long_column_stripes_two_devices(monkeypatch):
     # the same GPU listed twice: stripes alternate between two device entries of the context
     from bio_amd import _native, pack_sequences, score_table
