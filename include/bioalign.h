@@ -192,13 +192,18 @@ int bioalign_plan_share_pack(bioalign_plan *plan, const bioalign_plan *packed_by
  * the intra-sequence kernels -- rows spread over the lanes of many wavefronts, anti-diagonal
  * wavefront, strips pipelined through HBM -- which is what a single long pair needs
  * (AlignGlobalLS, align_linear.go:9, on inputs the per-lane batch kernels would crawl through;
- * AlignPair in its four modes, align_pair.go:3, and AlignLocal, align.go:152, likewise).  Linear
- * gaps, at most 64 distinct column symbols; anything else answers BIOALIGN_EUNSUPPORTED.  Runs on
+ * AlignPair in its four modes, align_pair.go:3, and AlignLocal, align.go:152, likewise; with
+ * gap_open != gap_extend Gotoh's three levels, align_affine.go:12, in four modes).  At most 64
+ * distinct column symbols; anything else answers BIOALIGN_EUNSUPPORTED.  A pair whose traceback
+ * matrix exceeds BIOALIGN_LONG_RESIDUE_BYTES (default: 70 % of the device's free memory) is traced
+ * back in linear space -- one DP pass without the matrix, then row blocks recomputed from kept
+ * rows and walked bottom-up: same traces, at most twice the cells (linear gaps, global / fitting /
+ * overlap; otherwise BIOALIGN_ENOMEM).  Runs on
  * the first device of the context -- unless the traceback matrix of a pair (up to one byte per
  * cell) would not fit that device and the context holds several: the matrix is then cut into
  * column stripes, one per device in turn, each stripe's last column handed to the next in row
  * blocks by device-to-device copies (BIOALIGN_LONG_STRIPES=<count> forces a number of stripes;
- * stripes that share a device run in one launch; local mode always runs unstriped).
+ * stripes that share a device run in one launch; local mode and affine gaps always run unstriped).
  * kernel_ms (may be NULL) receives the DP + traceback time in milliseconds.
  */
 int bioalign_long(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *out, float *kernel_ms);
