@@ -1357,6 +1357,10 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     (void)hipEventDestroy(e1);
     if (le != hipSuccess) return ctx->fail(BIOALIGN_EHIP, "long-mode kernels failed: %s", hipGetErrorString(le));
     if (dp_ms) *dp_ms += ms;
+    if (env_u64("BIOALIGN_TIMING", 0) > 1) {
+        const uint32_t *mw = reinterpret_cast<const uint32_t *>(misc);
+        fprintf(stderr, "bioalign_long: %.3f ms, walk: %u moves, %u tile requests, %u rounds\n", ms, mw[8 + 2], mw[8 + 6], mw[8 + 7]);
+    }
     if ((uint32_t)misc[0] != 0)
         return ctx->fail(BIOALIGN_EHIP, "long mode: a strip gave up waiting for the strip above it (%u waits ran out)",
                          (unsigned)(uint32_t)misc[0]);

@@ -81,6 +81,9 @@ struct BaLongWaveLds {
 };
 
 #define BA_LONG_RING (BA_LONG_RB * 64)  // columns a hand-over ring holds
+#ifndef BA_WALK_TW
+#define BA_WALK_TW 128                  // residue words (x 64 lanes) the walk stages per tile
+#endif
 
 // One step of one lane: T cells of one column.  `pw` holds the substitution scores of the lane's T rows against this
 // column's symbol, one signed byte per row (from the lane's strip profile in LDS): the byte is an SDWA operand of the add.
@@ -793,18 +796,31 @@ __global__ void __launch_bounds__(1024) ba_long_local_find_kernel(BaLongParams P
 
 // CKPT: the walk of one recomputed row block of the linear-space traceback (first_strip, stop_row).
 template <int MODE, int T, int K, bool CKPT = false>
-__global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
+__global__ void __launch_bounds__(256) ba_long_walk_kernel(BaLongParams P)
 {
     using G = BaLongGeom<T, K>;
     constexpr int RS = G::RS, CPD = G::CPD;
     constexpr uint32_t MASK = (1u << K) - 1u;
-    __shared__ uint32_t tile[64 * 64];
-    __shared__ uint32_t above[64];
-    const int lane = threadIdx.x;
+    // Four wavefronts: wave 0 walks, waves 1-3 load residue words for it -- a tile of BA_WALK_TW words x 64 lanes of a
+    // strip (a strip's whole passage fits one) with lane 63 of the strip above around the column where the walk will
+    // cross into it.  One CU pulls cold lines at about 12 GB/s (a 32 KB tile: 3-4 us), so the tile of the NEXT strip is
+    // fetched into a second buffer while the walk is still in the current one: where the walk will enter it follows
+    // from its diagonal, and a walk that drifts out of the prediction falls back to a load it waits for.
+    extern __shared__ __align__(16) uint32_t walk_lds[];
+    constexpr int TW = BA_WALK_TW;
+    uint32_t *buf0 = walk_lds, *buf1 = walk_lds + (TW * 64 + TW);  // two buffers: tile [TW][64], then above [TW]
+    // mailbox: [0] sequence number of the request, [1] what to load (0: leave), [2..5] where from, [6] buffer, [7] done count
+    int *mail = reinterpret_cast<int *>(walk_lds + 2 * (TW * 64 + TW));
+    uint32_t *tile = buf0, *above = buf0 + TW * 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = (int)P.n, m = (int)P.m, g = P.gap;
     const int strips = (int)P.strips;
     const int front = strips * RS - n;
     const int wps = (int)P.words_per_strip;
+    if (tid < 8) mail[tid] = 0;
+    __syncthreads();  // (the only barrier)
 
     const int b_top = (MODE == BA_FITTING) ? g : 0;
     const int b_left = (MODE == BA_OVERLAP) ? g : 0;
@@ -870,7 +886,7 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
     j = __builtin_amdgcn_readfirstlane(j);
     cur = __builtin_amdgcn_readfirstlane(cur);
     bv = __builtin_amdgcn_readfirstlane(bv);
-    if (lane == 0) {
+    if (tid == 0) {
         if (P.start_j < 0 && MODE != BA_LOCAL) *P.score = (int64_t)cur - (int64_t)g * (i + col0 + j);
         P.walk[0] = (uint32_t)i;  // where the walk starts
         P.walk[1] = (uint32_t)j;
@@ -884,23 +900,122 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
     // residue tiles
     int tile_s = -1, tile_u = 0;   // strip and first word index of `tile`
     int ab_s = -1, ab_u = 0;       // strip and first word index of `above` (lane 63 of that strip)
-    auto load_tile = [&](int s, int u) {
-        tile_s = s;
-        tile_u = max(0, min(u - 55, wps - 64));  // the walk moves towards smaller words
-        const uint32_t *src = P.resid + ((size_t)(s - first_strip) * wps + tile_u) * 64;
-        const int words = min(64, wps - tile_u);
-        // all 64 loads in flight at once: one memory latency per tile, not eight
-        uint32_t v[64];
+    auto mload = [](int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    if (wave != 0) {
+        // loaders: take one request after the other from the mailbox (the arguments are written before the sequence
+        // number, the words before the done count: one wavefront's LDS operations are carried out in order)
+        int seen = 0;
+        for (;;) {
+            int sq;
+            while ((sq = mload(&mail[0])) == seen) __builtin_amdgcn_s_sleep(2);
+            seen = sq;
+            asm volatile("" ::: "memory");
+            const int op = mail[1];
+            if (op == 0) break;
+            uint32_t *tb = mail[6] ? buf1 : buf0;
+            if (op & 1) {
+                const int sx = mail[2], tu = mail[3];
+                const uint32_t *src = P.resid + ((size_t)(sx - first_strip) * wps + tu) * 64;
+                const int words = min(TW, wps - tu);
+                constexpr int PER = (TW + 2) / 3;
+                uint32_t v[PER];
 #pragma unroll
-        for (int q = 0; q < 64; ++q) v[q] = src[(size_t)min(q, words - 1) * 64 + lane];
+                for (int q = 0; q < PER; ++q) v[q] = src[(size_t)min((wave - 1) * PER + q, words - 1) * 64 + lane];
 #pragma unroll
-        for (int q = 0; q < 64; ++q) tile[q * 64 + lane] = v[q];
+                for (int q = 0; q < PER; ++q)
+                    if ((wave - 1) * PER + q < TW) tb[((wave - 1) * PER + q) * 64 + lane] = v[q];
+            }
+            if (op & 2) {
+                const int sx = mail[4], au = mail[5];
+                for (int x = tid - 64; x < TW; x += 192) {
+                    const int uu = au + x;
+                    tb[TW * 64 + x] = uu < wps ? P.resid[((size_t)(sx - first_strip) * wps + uu) * 64 + 63] : 0u;
+                }
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&mail[7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    uint32_t n_requests = 0, n_rounds = 0;  // (synchronous requests and rounds, reported in P.walk[6], [7]: BIOALIGN_TIMING=2 prints them)
+    int posted = 0;  // requests posted so far
+    int cbuf = 0;    // the buffer the walk reads
+    bool pf_valid = false;  // the other buffer is being filled with (pf_s, pf_tu) and (pf_as, pf_au)
+    int pf_s = -1, pf_tu = 0, pf_as = -1, pf_au = 0;
+    auto post = [&](int op, int b, int sx, int tu, int as, int au) {
+        ++posted;
+        if (lane == 0) {
+            mail[1] = op;
+            mail[2] = sx;
+            mail[3] = tu;
+            mail[4] = as;
+            mail[5] = au;
+            mail[6] = b;
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&mail[0], posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     };
-    auto load_above = [&](int s, int u) {
-        ab_s = s;
-        ab_u = max(0, min(u - 55, wps - 64));
-        const int uu = ab_u + lane;
-        above[lane] = uu < wps ? P.resid[((size_t)(s - first_strip) * wps + uu) * 64 + 63] : 0u;
+    auto wait_all = [&]() {
+        while (mload(&mail[7]) != 3 * posted) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    auto use_buffer = [&](int b) {
+        cbuf = b;
+        tile = b ? buf1 : buf0;
+        above = tile + TW * 64;
+    };
+    auto clampw = [&](int u0) { return max(0, min(u0, wps - TW)); };
+    auto window = [&](int u) { return clampw(u - (TW - 9)); };  // the walk moves towards smaller words
+    // the column the walk reaches the last row of strip sx - 1 in if it keeps to its diagonal
+    auto cross_col = [&](int sx) { return max(j - (i - (sx * RS - front)), 1); };
+    auto entry_word = [&](int jc) { return ((jc - 1) + 63) / CPD; };  // lane 63 at column jc
+    auto load_tile = [&](int sx, int u) {
+        wait_all();
+        if (pf_valid && pf_s == sx && u >= pf_tu && u < pf_tu + TW) {
+            use_buffer(cbuf ^ 1);  // the words are there already
+            tile_s = pf_s;
+            tile_u = pf_tu;
+            ab_s = pf_as;
+            ab_u = pf_au;
+        } else {
+            ++n_requests;
+            tile_s = sx;
+            tile_u = window(u);
+            int op = 1;
+            if (sx - 1 >= first_strip && sx >= 1) {  // with lane 63 of the strip above, around where the walk will cross
+                ab_s = sx - 1;
+                ab_u = clampw(entry_word(cross_col(sx)) - TW / 2);
+                op |= 2;
+            }
+            post(op, cbuf ^ 1, tile_s, tile_u, ab_s, ab_u);
+            wait_all();
+            use_buffer(cbuf ^ 1);
+        }
+        pf_valid = false;
+        if (sx - 1 >= first_strip && sx >= 1) {
+            // meanwhile the loaders fetch the tile of the strip above into the other buffer
+            const int jc = cross_col(sx);
+            pf_s = sx - 1;
+            pf_tu = clampw(entry_word(jc) - (TW - 24));
+            int op = 1;
+            pf_as = -1;
+            pf_au = 0;
+            if (sx - 2 >= first_strip && sx >= 2) {
+                pf_as = sx - 2;
+                pf_au = clampw(entry_word(max(jc - RS, 1)) - TW / 2);
+                op |= 2;
+            }
+            post(op, cbuf ^ 1, pf_s, pf_tu, pf_as, pf_au);
+            pf_valid = true;
+        }
+    };
+    auto load_above = [&](int sx, int u) {
+        ++n_requests;
+        wait_all();
+        ab_s = sx;
+        ab_u = window(u);
+        post(2, cbuf, 0, 0, ab_s, ab_u);
+        wait_all();
     };
     // residue of cell (ii, jj), 0 <= ii <= n, 0 <= jj <= m
     auto residue = [&](int ii, int jj) -> uint32_t {
@@ -914,11 +1029,11 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
         const uint32_t sh = (uint32_t)(((t % CPD) * T + r) * K);
         uint32_t word;
         if (s == tile_s || tile_s < 0 || l != 63) {
-            if (s != tile_s || u < tile_u || u >= tile_u + 64) load_tile(s, u);
+            if (s != tile_s || u < tile_u || u >= tile_u + TW) load_tile(s, u);
             word = tile[(u - tile_u) * 64 + l];
         } else {
             // a cell of the strip above the one the walk is in: always its last lane
-            if (s != ab_s || u < ab_u || u >= ab_u + 64) load_above(s, u);
+            if (s != ab_s || u < ab_u || u >= ab_u + TW) load_above(s, u);
             word = above[u - ab_u];
         }
         // every lane read the same word: say so, and the whole walk runs on the scalar unit
@@ -944,11 +1059,11 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
         const uint32_t sh = (uint32_t)(((t % CPD) * T + r) * K);
         uint32_t word = 0;
         if (s == tile_s || l != 63) {
-            const bool in = (s == tile_s) && u >= tile_u && u < tile_u + 64;
+            const bool in = (s == tile_s) && u >= tile_u && u < tile_u + TW;
             ok = ok && in;
             word = tile[(in ? (u - tile_u) : 0) * 64 + l];
         } else {
-            const bool in = (s == ab_s) && u >= ab_u && u < ab_u + 64;
+            const bool in = (s == ab_s) && u >= ab_u && u < ab_u + TW;
             ok = ok && in;
             word = above[in ? (u - ab_u) : 0];
         }
@@ -984,6 +1099,7 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
     // Lane q looks at cell (i - q, j - q): the cells of a diagonal run are evaluated together, and
     // one round of LDS reads advances the walk by the whole run plus the move that ends it.
     while (i > stop_row && j > 0) {
+        ++n_rounds;
         const int ii = i - lane, jj = j - lane;
         bool ok = ii > stop_row && jj >= 1;
         uint32_t rcq = 0, ruq = 0, rlq = 0, rdq = 0;
@@ -1070,12 +1186,16 @@ __global__ void __launch_bounds__(64) ba_long_walk_kernel(BaLongParams P)
         emit_run(BA_MV_LEFT, (uint32_t)j);
         j = 0;
     }
+    wait_all();
+    post(0, 0, 0, 0, 0, 0);  // the loaders may leave
     if (lane == 0) {
         if (fill > 0) ops[k >> 4] = (uint32_t)opacc;
         if (fill > 16) ops[(k >> 4) + 1] = (uint32_t)(opacc >> 32);
         P.walk[2] = k + fill;  // trace length
         P.walk[4] = (uint32_t)i;  // where the walk stopped: (0, .) or (., 0) -- the next stripe's (i, its m)
         P.walk[5] = (uint32_t)j;
+        P.walk[6] = n_requests;
+        P.walk[7] = n_rounds;
     }
 }
 
@@ -1515,10 +1635,16 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
             hipLaunchKernelGGL((ba_long_local_find_kernel<T, K>), dim3(1), dim3(1024), 0, st, P);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
-        if (P.first_strip || P.stop_row)
-            hipLaunchKernelGGL((ba_long_walk_kernel<MODE, T, K, true>), dim3(1), dim3(64), 0, st, P);
-        else
-            hipLaunchKernelGGL((ba_long_walk_kernel<MODE, T, K>), dim3(1), dim3(64), 0, st, P);
+        const size_t walk_lds = (size_t)(2 * (BA_WALK_TW * 64 + BA_WALK_TW) + 8) * 4;
+        if (P.first_strip || P.stop_row) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_walk_kernel<MODE, T, K, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
+            hipLaunchKernelGGL((ba_long_walk_kernel<MODE, T, K, true>), dim3(1), dim3(256), walk_lds, st, P);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_walk_kernel<MODE, T, K>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
+            hipLaunchKernelGGL((ba_long_walk_kernel<MODE, T, K>), dim3(1), dim3(256), walk_lds, st, P);
+        }
         if ((e = hipGetLastError()) != hipSuccess || P.score_only || P.scan_only) return e;
         hipLaunchKernelGGL(ba_long_expand_kernel, dim3(1), dim3(1024), 0, st, P);
         e = hipGetLastError();
