@@ -1102,6 +1102,52 @@ __global__ void __launch_bounds__(256) ba_long_walk_kernel(BaLongParams P)
         ++n_rounds;
         const int ii = i - lane, jj = j - lane;
         bool ok = ii > stop_row && jj >= 1;
+        if (MODE != BA_LOCAL) {
+            // The common round, with the index arithmetic of the three residues shared: cell (ii, jj) lies in the staged
+            // tile, its left neighbour one step earlier in the same lane, its upper neighbour in the same word (same
+            // lane, row above) or -- first row of a lane -- one step earlier in the lane above (`above` for lane 0).
+            // Lanes this does not cover are left to the next round; when it does not cover the walk's own cell the
+            // general code below takes the round.
+            const int tt = ii - 1 + front;
+            const int sx = tt / RS, rem = tt % RS, l = rem / T, r = rem % T;
+            const int t = (jj - 1) + l, t1 = t - 1;
+            const int u = t / CPD, f = t % CPD, u1 = t1 / CPD, f1 = t1 % CPD;
+            const bool from_above = (r == 0 && l == 0);
+            const int tu_ = from_above ? (jj - 1) + 63 : t1;  // the step the row above was at in this column
+            const int uu_ = tu_ / CPD, fu_ = tu_ % CPD;
+            const bool fast = ok && ii >= 2 && jj >= 2 && sx == tile_s && u1 >= tile_u && u < tile_u + TW &&
+                              (!from_above || (sx - 1 >= first_strip && ab_s == sx - 1 && uu_ >= ab_u && uu_ < ab_u + TW));
+            const uint64_t fmask = __ballot(fast);
+            if (fmask & 1ull) {
+                uint32_t wA = 0, w1 = 0, w2 = 0;
+                if (fast) {
+                    wA = tile[(u - tile_u) * 64 + l];
+                    w1 = tile[(u1 - tile_u) * 64 + l];
+                    w2 = r > 0 ? wA : from_above ? above[uu_ - ab_u] : tile[(uu_ - tile_u) * 64 + l - 1];
+                }
+                const uint32_t rA = (wA >> (uint32_t)((f * T + r) * K)) & MASK;
+                const uint32_t rL = (w1 >> (uint32_t)((f1 * T + r) * K)) & MASK;
+                const uint32_t rU = r > 0 ? (wA >> (uint32_t)((f * T + r - 1) * K)) & MASK
+                                          : (w2 >> (uint32_t)((fu_ * T + T - 1) * K)) & MASK;
+                const bool a_up = rA != rU, a_left = rA != rL;
+                const uint64_t dmask = __ballot(fast && a_up && a_left);
+                const uint32_t run = dmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~dmask);
+                emit_run(BA_MV_DIAG, run);
+                i -= (int)run;
+                j -= (int)run;
+                if (run < 64 && ((fmask >> run) & 1ull)) {
+                    const uint64_t lmask = __ballot(!a_left && a_up);
+                    if ((lmask >> run) & 1ull) {
+                        emit(BA_MV_LEFT);
+                        --j;
+                    } else {
+                        emit(BA_MV_UP);
+                        --i;
+                    }
+                }
+                continue;
+            }
+        }
         uint32_t rcq = 0, ruq = 0, rlq = 0, rdq = 0;
         if (ok) {
             rcq = peek(ii, jj, ok);
