@@ -1342,6 +1342,19 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
             cj = mw[8 + 5];
             hi = lo;
         }
+        if (le == hipSuccess && mw[0] == 0 && (ci > 0 || cj > 0)) {
+            // the walk has reached (or started on) the matrix' left or top border: what remains are the border's own moves
+            // (align.go:92-100; align_pair.go:110-113, 158-159, 187-188), which the walk emits without reading a residue
+            BaLongParams Pb = P;
+            Pb.start_i = (int)ci;
+            Pb.start_j = (int)cj;
+            Pb.trace_done = (uint32_t)done;
+            Pb.trace_cap = cap;
+            le = ba_launch_long(Pb, in->mode, T, K, BA_LONG_PHASE_WALK, st);
+            if (le == hipSuccess) le = hipMemcpyAsync(misc, d_misc.p, 64, hipMemcpyDeviceToHost, st);
+            if (le == hipSuccess) le = hipStreamSynchronize(st);
+            done += mw[8 + 2];
+        }
         misc[1] = (uint64_t)score_seen;  // (the blocks' walks start from a given cell and leave the score alone)
         if (le == hipSuccess && done == 0) {  // a walk of no moves (cannot happen for n, m >= 1 in these modes)
             misc[2] = cap;

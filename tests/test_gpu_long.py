@@ -260,6 +260,12 @@ def test_long_linear_space_traceback(budget, monkeypatch):
     for x, y in [(junk(2500) + core, core + junk(400)), (core + junk(2600), junk(500) + core), (junk(1500) + core + junk(1500), core)]:
         for mode in ("global", "fitting", "overlap"):
             assert bio_amd.AlignPairLong(mode, x, y, a, 1) == O.AlignPair(mode, x, y, oa, 1), (mode, len(x), len(y))
+    # an end cell ON the left border (fitting with a free gap: the bottom row's leftmost maximum is column 0): the trace is
+    # the border's own moves (found by tools/fuzz_parity.py --long)
+    z, oz = bio_amd.MatchAligner(0, -2), O.MatchAligner(0, -2)
+    x, y = junk(780), junk(1000)
+    for mode in ("global", "fitting", "overlap"):
+        assert bio_amd.AlignPairLong(mode, x, y, z, 0) == O.AlignPair(mode, x, y, oz, 0), mode
     # what the linear-space traceback does not cover says so
     with pytest.raises(bio_amd._native.BioAlignError) as e:
         bio_amd.AlignPairLong("local", junk(5000), junk(5000), a, 1)  # 6.5 MB of residues

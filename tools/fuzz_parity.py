@@ -5,7 +5,7 @@ spend GPU minutes on looking for inputs the fixed tests do not cover.
 
 usage: python tools/fuzz_parity.py --seconds 240 --seed 1
 """
-import argparse
+import argparse, collections
 import os
 import sys
 import time
@@ -141,40 +141,70 @@ def main():
         print(f"done: {k} FASTA texts, both readers (buffers 16 / 200 / 4096), all equal (seed {args.seed})", flush=True)
         return
     if args.long:
-        if args.stripes:
-            os.environ["BIOALIGN_LONG_STRIPES"] = str(args.stripes)
-        k = 0
+        # long mode: four modes, linear and affine gaps, DNA / few-letter / protein alphabets; per pair one of: plain,
+        # column stripes in one launch, column stripes in host-driven row blocks, linear-space traceback (tiny budget)
+        k = aff = 0
+        variants = collections.Counter()
         al = np.frombuffer(b"ACGT", dtype=np.uint8)
+        prot = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
         while time.time() < t_end:
             hi = int(rng.choice([70, 600, 1500, 4000]))
             n, m = int(rng.integers(1, hi + 1)), int(rng.integers(1, hi + 1))
-            nsym = int(rng.integers(1, 5))
-            a = al[rng.integers(0, nsym, n)]
+            protein = rng.integers(0, 4) == 0
+            alpha = prot if protein else al[:int(rng.integers(1, 5))]
+            a = alpha[rng.integers(0, len(alpha), n)]
             if rng.integers(0, 2):
                 b = a.copy()
                 for _ in range(int(rng.integers(0, 30))):
                     p = int(rng.integers(0, max(len(b), 1)))
-                    b = np.delete(b, p) if rng.integers(0, 2) and len(b) > 1 else np.insert(b, p, al[rng.integers(0, nsym)])
+                    if rng.integers(0, 2) and len(b) > 1:
+                        w = int(rng.integers(1, 40)) if rng.integers(0, 3) == 0 else 1  # long gaps too
+                        b = np.delete(b, slice(p, p + w)) if len(b) > w else b
+                    else:
+                        b = np.insert(b, p, alpha[rng.integers(0, len(alpha), int(rng.integers(1, 20)) if rng.integers(0, 3) == 0 else 1)])
                 b = b[:max(m, 1)]
             else:
-                b = al[rng.integers(0, nsym, m)]
+                b = alpha[rng.integers(0, len(alpha), m)]
             x, y = a.tobytes(), b.tobytes()
-            match, mismatch, gap = int(rng.integers(0, 4)), -int(rng.integers(0, 4)), int(rng.integers(0, 5))
-            mode = ("global", "fitting", "overlap")[int(rng.integers(0, 3))]
+            if protein and rng.integers(0, 3):
+                name = str(rng.choice(["Blosum62", "Pam250"]))
+                pa, oa = getattr(bio_amd, name), getattr(O, name)()
+                gap = int(rng.integers(1, 12))
+            else:
+                match, mismatch, gap = int(rng.integers(0, 4)), -int(rng.integers(0, 4)), int(rng.integers(0, 5))
+                pa, oa = bio_amd.MatchAligner(match, mismatch), O.MatchAligner(match, mismatch)
+            mode = ("global", "local", "fitting", "overlap")[int(rng.integers(0, 4))]
+            affine = rng.integers(0, 3) == 0
+            ge = int(rng.integers(0, gap + 1)) if affine else gap
+            affine = affine and ge != gap
+            for var in ("BIOALIGN_LONG_STRIPES", "BIOALIGN_STRIPE_MERGED", "BIOALIGN_STRIPE_BLOCKS", "BIOALIGN_LONG_RESIDUE_BYTES"):
+                os.environ.pop(var, None)
+            variant = "plain"
+            if not affine and mode != "local":
+                variant = str(rng.choice(["plain", "merged", "blocks", "linear-space"])) if not args.stripes else "merged"
+                if variant in ("merged", "blocks"):
+                    os.environ["BIOALIGN_LONG_STRIPES"] = str(args.stripes or int(rng.integers(2, 6)))
+                    os.environ["BIOALIGN_STRIPE_MERGED"] = "1" if variant == "merged" else "0"
+                    os.environ["BIOALIGN_STRIPE_BLOCKS"] = str(int(rng.integers(1, 5)))
+                elif variant == "linear-space":
+                    os.environ["BIOALIGN_LONG_RESIDUE_BYTES"] = str(int(rng.choice([1, 400_000])))
             try:
-                got = bio_amd.AlignPairLong(mode, x, y, bio_amd.MatchAligner(match, mismatch), gap)
+                got = bio_amd.AlignAffinePairLong(mode, x, y, pa, gap, ge) if affine else bio_amd.AlignPairLong(mode, x, y, pa, gap)
             except _native.BioAlignError as e:
                 if e.code == _native.EUNSUPPORTED:
                     continue
                 raise
-            want = O.AlignPair(mode, x, y, O.MatchAligner(match, mismatch), gap)
+            want = O.AlignAffine(mode, x, y, oa, gap, ge) if affine else O.AlignPair(mode, x, y, oa, gap)
             if got != want:
-                print("MISMATCH", dict(mode=mode, match=match, mismatch=mismatch, gap=gap, s1=x, s2=y, want_score=want[0], got_score=got[0]), flush=True)
+                print("MISMATCH", dict(mode=mode, variant=variant, gap=gap, ge=ge, env={v: os.environ.get(v) for v in os.environ if v.startswith("BIOALIGN")},
+                                       s1=x, s2=y, want_score=want[0], got_score=got[0]), flush=True)
                 sys.exit(1)
             k += 1
+            aff += int(affine)
+            variants[variant] += 1
             if k % 100 == 0:
                 print(f"{k} long pairs, all equal", flush=True)
-        print(f"done: {k} long pairs, all equal (seed {args.seed}, stripes {args.stripes})", flush=True)
+        print(f"done: {k} long pairs, all equal (seed {args.seed}; {aff} affine; {dict(variants)})", flush=True)
         return
     batches = pairs = unsupported = 0
     eng = bio_amd.engine()
