@@ -1149,7 +1149,39 @@ __global__ void __launch_bounds__(256) ba_long_walk_kernel(BaLongParams P)
             }
         }
         uint32_t rcq = 0, ruq = 0, rlq = 0, rdq = 0;
-        if (ok) {
+        bool have = false;
+        if (MODE == BA_LOCAL) {
+            // the common round of local mode: as above, plus the diagonal neighbour (one step before the upper one)
+            const int tt = ii - 1 + front;
+            const int sx = tt / RS, rem = tt % RS, l = rem / T, r = rem % T;
+            const int t = (jj - 1) + l, t1 = t - 1;
+            const int u = t / CPD, f = t % CPD, u1 = t1 / CPD, f1 = t1 % CPD;
+            const bool from_above = (r == 0 && l == 0);
+            const int tu_ = from_above ? (jj - 1) + 63 : t1;
+            const int uu_ = tu_ / CPD, fu_ = tu_ % CPD;
+            const int tx_ = tu_ - 1, ux_ = tx_ / CPD, fx_ = tx_ % CPD;
+            const bool fast = ok && ii >= 2 && jj >= 2 && sx == tile_s && u1 >= tile_u && u < tile_u + TW &&
+                              (!from_above || (ab_s == sx - 1 && ux_ >= ab_u && uu_ < ab_u + TW)) &&
+                              (r > 0 || from_above || ux_ >= tile_u);
+            if (__ballot(fast) & 1ull) {
+                uint32_t wA = 0, w1 = 0, w2 = 0, w3 = 0;
+                if (fast) {
+                    wA = tile[(u - tile_u) * 64 + l];
+                    w1 = tile[(u1 - tile_u) * 64 + l];
+                    if (r == 0) {
+                        w2 = from_above ? above[uu_ - ab_u] : tile[(uu_ - tile_u) * 64 + l - 1];
+                        w3 = from_above ? above[ux_ - ab_u] : tile[(ux_ - tile_u) * 64 + l - 1];
+                    }
+                }
+                rcq = (wA >> (uint32_t)((f * T + r) * K)) & MASK;
+                rlq = (w1 >> (uint32_t)((f1 * T + r) * K)) & MASK;
+                ruq = r > 0 ? (wA >> (uint32_t)((f * T + r - 1) * K)) & MASK : (w2 >> (uint32_t)((fu_ * T + T - 1) * K)) & MASK;
+                rdq = r > 0 ? (w1 >> (uint32_t)((f1 * T + r - 1) * K)) & MASK : (w3 >> (uint32_t)((fx_ * T + T - 1) * K)) & MASK;
+                ok = fast;
+                have = true;
+            }
+        }
+        if (!have && ok) {
             rcq = peek(ii, jj, ok);
             ruq = peek(ii - 1, jj, ok);
             rlq = peek(ii, jj - 1, ok);
