@@ -1544,6 +1544,19 @@ __global__ void __launch_bounds__(64) ba_long_walk_affine_kernel(BaLongParams P)
                 // above), then a gap in s1 (align_affine.go:82-100)
                 const uint32_t nb_ = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)run);
                 level = (nb_ & 8u) ? LV_G1 : LV_G2;
+                // the gap's first move is decided by the same cell's open bit, which is at hand: a gap of length 1 -- most
+                // of them -- is taken here and the walk stays on the middle level (i, j >= 1 in this cell)
+                if (level == LV_G2 && (i == 1 || (nb_ & 1u))) {
+                    emit_run(BA_MV_UP, 1);
+                    --i;
+                    if (MODE == BA_LOCAL) V += go;
+                    level = LV_MM;
+                } else if (level == LV_G1 && (j == 1 || (nb_ & 2u))) {
+                    emit_run(BA_MV_LEFT, 1);
+                    --j;
+                    if (MODE == BA_LOCAL) V += go;
+                    level = LV_MM;
+                }
             }
         } else if (level == LV_G1) {
             // gap in s1: (gap, s2[j-1]) per move, j >= 1; the gap was opened at column 1, on the top border only there,
