@@ -1344,13 +1344,21 @@ __global__ void __launch_bounds__(1024) ba_long_affine_find_kernel(BaLongParams 
 }
 
 template <int MODE, int T>
-__global__ void __launch_bounds__(64) ba_long_walk_affine_kernel(BaLongParams P)
+__global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P)
 {
     using G = BaLongGeom<T, 4>;
     constexpr int RS = G::RS, CPD = G::CPD;
-    __shared__ uint32_t tile[64 * 64];
-    __shared__ uint32_t above[64];
-    const int lane = threadIdx.x;
+    // wave 0 walks, waves 1-3 load decision words for it, the next strip's tile ahead of the walk (see ba_long_walk_kernel)
+    extern __shared__ __align__(16) uint32_t walk_lds[];
+    constexpr int TW = BA_WALK_TW;
+    uint32_t *buf0 = walk_lds, *buf1 = walk_lds + (TW * 64 + TW);
+    int *mail = reinterpret_cast<int *>(walk_lds + 2 * (TW * 64 + TW));
+    uint32_t *tile = buf0, *above = buf0 + TW * 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 8) mail[tid] = 0;
+    __syncthreads();  // (the only barrier)
     const int n = (int)P.n, m = (int)P.m;
     const int go = P.gap, ge = P.gap_ext, cc = go - ge;
     const int strips = (int)P.strips;
@@ -1396,7 +1404,7 @@ __global__ void __launch_bounds__(64) ba_long_walk_affine_kernel(BaLongParams P)
     i = __builtin_amdgcn_readfirstlane(i);
     j = __builtin_amdgcn_readfirstlane(j);
     V = __builtin_amdgcn_readfirstlane(V);
-    if (lane == 0) {
+    if (tid == 0) {
         if (MODE != BA_LOCAL) *P.score = (int64_t)V;
         P.walk[0] = (uint32_t)i;
         P.walk[1] = (uint32_t)j;
@@ -1409,22 +1417,114 @@ __global__ void __launch_bounds__(64) ba_long_walk_affine_kernel(BaLongParams P)
 
     // staged decision words (the tiles of ba_long_walk_kernel)
     int tile_s = -1, tile_u = 0, ab_s = -1, ab_u = 0;
-    auto load_tile = [&](int s, int u) {
-        tile_s = s;
-        tile_u = max(0, min(u - 55, wps - 64));
-        const uint32_t *src = P.resid + ((size_t)s * wps + tile_u) * 64;
-        const int words = min(64, wps - tile_u);
-        uint32_t v[64];
+    auto mload = [](int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    if (wave != 0) {
+        int seen = 0;
+        for (;;) {
+            int sq;
+            while ((sq = mload(&mail[0])) == seen) __builtin_amdgcn_s_sleep(2);
+            seen = sq;
+            asm volatile("" ::: "memory");
+            const int op = mail[1];
+            if (op == 0) break;
+            uint32_t *tb = mail[6] ? buf1 : buf0;
+            if (op & 1) {
+                const int sx = mail[2], tu = mail[3];
+                const uint32_t *src = P.resid + ((size_t)sx * wps + tu) * 64;
+                const int words = min(TW, wps - tu);
+                constexpr int PER = (TW + 2) / 3;
+                uint32_t v[PER];
 #pragma unroll
-        for (int q = 0; q < 64; ++q) v[q] = src[(size_t)min(q, words - 1) * 64 + lane];
+                for (int q = 0; q < PER; ++q) v[q] = src[(size_t)min((wave - 1) * PER + q, words - 1) * 64 + lane];
 #pragma unroll
-        for (int q = 0; q < 64; ++q) tile[q * 64 + lane] = v[q];
+                for (int q = 0; q < PER; ++q)
+                    if ((wave - 1) * PER + q < TW) tb[((wave - 1) * PER + q) * 64 + lane] = v[q];
+            }
+            if (op & 2) {
+                const int sx = mail[4], au = mail[5];
+                for (int x = tid - 64; x < TW; x += 192) {
+                    const int uu = au + x;
+                    tb[TW * 64 + x] = uu < wps ? P.resid[((size_t)sx * wps + uu) * 64 + 63] : 0u;
+                }
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&mail[7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    int posted = 0, cbuf = 0;
+    bool pf_valid = false;
+    int pf_s = -1, pf_tu = 0, pf_as = -1, pf_au = 0;
+    auto post = [&](int op, int b, int sx, int tu, int as, int au) {
+        ++posted;
+        if (lane == 0) {
+            mail[1] = op;
+            mail[2] = sx;
+            mail[3] = tu;
+            mail[4] = as;
+            mail[5] = au;
+            mail[6] = b;
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&mail[0], posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     };
-    auto load_above = [&](int s, int u) {
-        ab_s = s;
-        ab_u = max(0, min(u - 55, wps - 64));
-        const int uu = ab_u + lane;
-        above[lane] = uu < wps ? P.resid[((size_t)s * wps + uu) * 64 + 63] : 0u;
+    auto wait_all = [&]() {
+        while (mload(&mail[7]) != 3 * posted) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    auto use_buffer = [&](int b) {
+        cbuf = b;
+        tile = b ? buf1 : buf0;
+        above = tile + TW * 64;
+    };
+    auto clampw = [&](int u0) { return max(0, min(u0, wps - TW)); };
+    auto window = [&](int u) { return clampw(u - (TW - 9)); };
+    auto cross_col = [&](int sx) { return max(j - (i - (sx * RS - front)), 1); };
+    auto entry_word = [&](int jc) { return ((jc - 1) + 63) / CPD; };
+    auto load_tile = [&](int sx, int u) {
+        wait_all();
+        if (pf_valid && pf_s == sx && u >= pf_tu && u < pf_tu + TW) {
+            use_buffer(cbuf ^ 1);
+            tile_s = pf_s;
+            tile_u = pf_tu;
+            ab_s = pf_as;
+            ab_u = pf_au;
+        } else {
+            tile_s = sx;
+            tile_u = window(u);
+            int op = 1;
+            if (sx >= 1) {
+                ab_s = sx - 1;
+                ab_u = clampw(entry_word(cross_col(sx)) - TW / 2);
+                op |= 2;
+            }
+            post(op, cbuf ^ 1, tile_s, tile_u, ab_s, ab_u);
+            wait_all();
+            use_buffer(cbuf ^ 1);
+        }
+        pf_valid = false;
+        if (sx >= 1) {
+            const int jc = cross_col(sx);
+            pf_s = sx - 1;
+            pf_tu = clampw(entry_word(jc) - (TW - 24));
+            int op = 1;
+            pf_as = -1;
+            pf_au = 0;
+            if (sx >= 2) {
+                pf_as = sx - 2;
+                pf_au = clampw(entry_word(max(jc - RS, 1)) - TW / 2);
+                op |= 2;
+            }
+            post(op, cbuf ^ 1, pf_s, pf_tu, pf_as, pf_au);
+            pf_valid = true;
+        }
+    };
+    auto load_above = [&](int sx, int u) {
+        wait_all();
+        ab_s = sx;
+        ab_u = window(u);
+        post(2, cbuf, 0, 0, ab_s, ab_u);
+        wait_all();
     };
     // stages what cell (ii, jj) needs, 1 <= ii <= n, 1 <= jj <= m (uniform)
     auto stage = [&](int ii, int jj) {
@@ -1432,8 +1532,8 @@ __global__ void __launch_bounds__(64) ba_long_walk_affine_kernel(BaLongParams P)
         const int s = tt / RS, l = (tt % RS) / T;
         const int u = ((jj - 1) + l) / CPD;
         if (s == tile_s || tile_s < 0 || l != 63) {
-            if (s != tile_s || u < tile_u || u >= tile_u + 64) load_tile(s, u);
-        } else if (s != ab_s || u < ab_u || u >= ab_u + 64) {
+            if (s != tile_s || u < tile_u || u >= tile_u + TW) load_tile(s, u);
+        } else if (s != ab_s || u < ab_u || u >= ab_u + TW) {
             load_above(s, u);
         }
     };
@@ -1446,11 +1546,11 @@ __global__ void __launch_bounds__(64) ba_long_walk_affine_kernel(BaLongParams P)
         const uint32_t sh = (uint32_t)(((t % CPD) * T + r) * 4);
         uint32_t word = 0;
         if (s == tile_s || l != 63) {
-            const bool in = (s == tile_s) && u >= tile_u && u < tile_u + 64;
+            const bool in = (s == tile_s) && u >= tile_u && u < tile_u + TW;
             ok = ok && in;
             word = tile[(in ? (u - tile_u) : 0) * 64 + l];
         } else {
-            const bool in = (s == ab_s) && u >= ab_u && u < ab_u + 64;
+            const bool in = (s == ab_s) && u >= ab_u && u < ab_u + TW;
             ok = ok && in;
             word = above[in ? (u - ab_u) : 0];
         }
@@ -1615,6 +1715,8 @@ __global__ void __launch_bounds__(64) ba_long_walk_affine_kernel(BaLongParams P)
             }
         }
     }
+    wait_all();
+    post(0, 0, 0, 0, 0, 0);  // the loaders may leave
     if (lane == 0) {
         if (fill > 0) ops[k >> 4] = (uint32_t)opacc;
         if (fill > 16) ops[(k >> 4) + 1] = (uint32_t)(opacc >> 32);
@@ -1778,7 +1880,11 @@ static hipError_t launch_long_affine(const BaLongParams &P, int phases, hipStrea
             hipLaunchKernelGGL((ba_long_affine_find_kernel<T>), dim3(1), dim3(1024), 0, st, P);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
-        hipLaunchKernelGGL((ba_long_walk_affine_kernel<MODE, T>), dim3(1), dim3(64), 0, st, P);
+        const size_t walk_lds = (size_t)(2 * (BA_WALK_TW * 64 + BA_WALK_TW) + 8) * 4;
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_walk_affine_kernel<MODE, T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds)) != hipSuccess)
+            return e;
+        hipLaunchKernelGGL((ba_long_walk_affine_kernel<MODE, T>), dim3(1), dim3(256), walk_lds, st, P);
         if ((e = hipGetLastError()) != hipSuccess || P.score_only) return e;
         hipLaunchKernelGGL(ba_long_expand_kernel, dim3(1), dim3(1024), 0, st, P);
         e = hipGetLastError();
