@@ -251,11 +251,25 @@ inline Alignment AlignGlobalLS(const Seq &s1, const Seq &s2, const Aligner &a, i
 }
 inline std::tuple<double, Seq, Seq> AlignGlobalAffine(const Seq &s1, const Seq &s2, const Aligner &a, double gapOpenPenalty,
                                                       double gapExtendPenalty)
-{  // align_affine.go:12-167: float64 score, integer arithmetic underneath (whole-number penalties)
-    if (gapOpenPenalty != (long long)gapOpenPenalty || gapExtendPenalty != (long long)gapExtendPenalty)
-        throw std::invalid_argument("AlignGlobalAffine on the GPU path needs integer-valued penalties");
-    Alignment r = detail::run("global", {s1}, {s2}, a, (int)gapOpenPenalty, (int)gapExtendPenalty, false)[0];
-    return {(double)r.score, r.t1, r.t2};
+{  // align_affine.go:12-167: float64 penalties and score, integer arithmetic underneath.  Fractional penalties are not
+   // truncated: multiples of 2^-e (e <= 6) run in units of 2^-e -- scores and penalties times 2^e, exact integer Gotoh,
+   // score divided back -- which is what the reference's float64 sums compute exactly; any other fraction is refused
+   // (there the reference's result depends on float64 rounding along the path).
+    int scale = 0;
+    for (int e = 0; e <= 6 && !scale; ++e) {
+        const double f = (double)(1 << e);
+        if (gapOpenPenalty * f == (double)(long long)(gapOpenPenalty * f) && gapExtendPenalty * f == (double)(long long)(gapExtendPenalty * f))
+            scale = 1 << e;
+    }
+    if (!scale) throw std::invalid_argument("AlignGlobalAffine on the GPU path needs penalties that are multiples of 1/64");
+    struct Scaled : Aligner {
+        const Aligner &a;
+        int k;
+        Scaled(const Aligner &a_, int k_) : a(a_), k(k_) {}
+        int Score(uint8_t x, uint8_t y) const override { return k * a.Score(x, y); }
+    } scaled(a, scale);
+    Alignment r = detail::run("global", {s1}, {s2}, scaled, (int)(gapOpenPenalty * scale), (int)(gapExtendPenalty * scale), false)[0];
+    return {(double)r.score / scale, r.t1, r.t2};
 }
 
 

@@ -92,6 +92,20 @@ static void gpu_tests()
         else resc += b.Score((uint8_t)t1[k], (uint8_t)t2[k]), open = 0;
     }
     CHECK(resc == sc, "affine rescoring: %g vs %g", resc, sc);
+    {   // fractional penalties run in units of the fraction, nothing is truncated (open 2.5, extend 0.5)
+        auto [fs, f1, f2] = bio::AlignGlobalAffine("ACDDE", "ACE", b, 2.5, 0.5);
+        double r2 = 0;
+        int op2 = 0;
+        for (size_t k = 0; k < f1.size(); ++k) {
+            if (f1[k] == '-') r2 -= (op2 == 1 ? 0.5 : 2.5), op2 = 1;
+            else if (f2[k] == '-') r2 -= (op2 == 2 ? 0.5 : 2.5), op2 = 2;
+            else r2 += b.Score((uint8_t)f1[k], (uint8_t)f2[k]), op2 = 0;
+        }
+        CHECK(r2 == fs && f1.size() == f2.size(), "fractional affine rescoring: %g vs %g", r2, fs);
+        bool refused = false;
+        try { bio::AlignGlobalAffine("ACDDE", "ACE", b, 0.1, 1); } catch (const std::invalid_argument &) { refused = true; }
+        CHECK(refused, "a penalty that is not a multiple of 1/64 is refused");
+    }
     threw = false;
     try { bio::AlignAffineBatch("global", {"ACGT"}, {"ACG"}, bio::MatchAligner(1, -1), 1, 3); } catch (const bio::Error &e) { threw = e.code == BIOALIGN_EUNSUPPORTED; }
     CHECK(threw, "open < extend fails loudly");
