@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--fasta", action="store_true", help="the FASTA parser (both readers' rules) on random texts")
     ap.add_argument("--long", action="store_true", help="long mode (bioalign_long) on single pairs instead of batches")
     ap.add_argument("--stripes", type=int, default=0, help="with --long: force this many column stripes")
+    ap.add_argument("--long-max", type=int, default=4000, help="with --long: largest sequence length drawn")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
@@ -148,7 +149,7 @@ def main():
         al = np.frombuffer(b"ACGT", dtype=np.uint8)
         prot = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
         while time.time() < t_end:
-            hi = int(rng.choice([70, 600, 1500, 4000]))
+            hi = int(rng.choice([70, 600, 1500, args.long_max]))
             n, m = int(rng.integers(1, hi + 1)), int(rng.integers(1, hi + 1))
             protein = rng.integers(0, 4) == 0
             alpha = prot if protein else al[:int(rng.integers(1, 5))]
