@@ -203,7 +203,7 @@ def AlignLocal(s1: bytes, s2: bytes, a, indelPenalty: int):
 
 def AlignPairLong(mode: str, s1: bytes, s2: bytes, a, indelPenalty: int):
     """AlignPair for ONE long pair: same result, computed by the intra-sequence wavefront
-    kernels (bioalign_long).  All four modes, linear gap, <= 64 distinct column symbols."""
+    kernels (bioalign_long).  All four modes, linear gap, <= 100 distinct column symbols."""
     if mode not in _native.MODES:
         return -1, None, None
     sc, t1, t2 = _run_batch(mode, [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty, long=True)
@@ -215,7 +215,7 @@ def AlignGlobalLS(s1: bytes, s2: bytes, a, indelPenalty: int):
     (panics, alternate tie-breaks); this one returns exactly AlignGlobal's result, which is what
     its author's disabled test asks for (align_test.go:55-66).  Pairs of LONG_MIN_CELLS cells
     or more go to the long-mode kernels when their parameters allow it."""
-    use_long = len(s1) * len(s2) >= LONG_MIN_CELLS and len(set(bytes(s2))) <= 64
+    use_long = len(s1) * len(s2) >= LONG_MIN_CELLS and len(set(bytes(s2))) <= 100
     sc, t1, t2 = _run_batch("global", [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty, long=use_long)
     return sc[0], t1[0], t2[0]
 

@@ -1431,9 +1431,9 @@ int long_geometry(bioalign_ctx *ctx, const bioalign_batch_t *in, uint64_t n, uin
 {
     const int g = in->gap_open;
     const int bias = in->mode == BIOALIGN_LOCAL ? g : 2 * g;  // what the profile adds to w (kernels_long.hip)
-    if (in->nb > 64)
+    if (in->nb > 100)  // (four strip profiles of 256 bytes per symbol next to 47 KB of rings in a CU's 160 KB)
         return ctx->fail(BIOALIGN_EUNSUPPORTED, "long mode keeps a strip profile of 256 bytes per column symbol and wavefront "
-                                                "in LDS: at most 64 distinct column symbols (got %d)", in->nb);
+                                                "in LDS: at most 100 distinct column symbols (got %d)", in->nb);
     int wmax = 0;
     for (int i = 0; i < in->na * in->nb; ++i) {
         const int64_t v = (int64_t)in->score_table[i] + bias;

@@ -193,8 +193,8 @@ int bioalign_plan_share_pack(bioalign_plan *plan, const bioalign_plan *packed_by
  * wavefront, strips pipelined through HBM -- which is what a single long pair needs
  * (AlignGlobalLS, align_linear.go:9, on inputs the per-lane batch kernels would crawl through;
  * AlignPair in its four modes, align_pair.go:3, and AlignLocal, align.go:152, likewise; with
- * gap_open != gap_extend Gotoh's three levels, align_affine.go:12, in four modes).  At most 64
- * distinct column symbols; anything else answers BIOALIGN_EUNSUPPORTED.  A pair whose traceback
+ * gap_open != gap_extend Gotoh's three levels, align_affine.go:12, in four modes).  At most 100
+ * distinct column symbols (64 with affine gaps); anything else answers BIOALIGN_EUNSUPPORTED.  A pair whose traceback
  * matrix exceeds BIOALIGN_LONG_RESIDUE_BYTES (default: 70 % of the device's free memory) is traced
  * back in linear space -- one DP pass without the matrix, then row blocks recomputed from kept
  * rows and walked bottom-up: same traces, at most twice the cells (linear gaps, global / fitting /

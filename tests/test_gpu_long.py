@@ -95,13 +95,26 @@ def test_long_several_strips_and_align_global_ls():
 def test_long_unsupported_fails_loudly():
     # what the long kernels do not cover is refused, not computed some other way: more than 64 column symbols, and
     # gap penalties with open < extend
-    x = bytes(range(40, 140)) * 3
+    x = bytes(range(40, 160)) * 3
     with pytest.raises(bio_amd._native.BioAlignError) as e:
-        bio_amd.AlignPairLong("global", x, x[::-1], bio_amd.MatchAligner(1, -1), 1)
+        bio_amd.AlignPairLong("global", x, x[::-1], bio_amd.MatchAligner(1, -1), 1)  # 120 column symbols (linear: <= 100)
+    assert e.value.code == bio_amd._native.EUNSUPPORTED
+    with pytest.raises(bio_amd._native.BioAlignError) as e:
+        bio_amd.AlignAffinePairLong("global", x[:240], x[:240][::-1], bio_amd.MatchAligner(1, -1), 3, 1)  # 80 (affine: <= 64)
     assert e.value.code == bio_amd._native.EUNSUPPORTED
     with pytest.raises(bio_amd._native.BioAlignError) as e:
         bio_amd.AlignAffinePairLong("global", b"ACGT" * 10, b"ACG" * 10, bio_amd.MatchAligner(1, -1), 1, 3)
     assert e.value.code == bio_amd._native.EUNSUPPORTED
+
+
+@pytest.mark.parametrize("mode", MODES4)
+def test_long_hundred_column_symbols(mode):
+    # the widest alphabet the linear long kernels take: four strip profiles of 25 KB each in LDS
+    rng = random.Random(61)
+    x = bytes(rng.randrange(46, 146) for _ in range(1500))
+    y = bytes(x[k] if rng.random() < 0.8 else rng.randrange(46, 146) for k in range(1400)) + bytes(range(46, 146))
+    a, oa = bio_amd.MatchAligner(2, -1), O.MatchAligner(2, -1)
+    assert bio_amd.AlignPairLong(mode, x, y, a, 2) == O.AlignPair(mode, x, y, oa, 2)
 
 
 def _affine_same(mode, x, y, a, oa, go, ge):
