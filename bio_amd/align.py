@@ -96,7 +96,13 @@ def pack_sequences(seqs):
     return data, off
 
 
-LONG_MIN_CELLS = 1 << 24  # AlignGlobalLS hands pairs of at least this many cells to the long-mode kernels
+LONG_MIN_CELLS = 1 << 24  # pairs of at least this many cells go to the long-mode kernels (bioalign_long)
+
+
+def _long_pair(s1, s2, max_symbols=100):
+    """One pair per matrix instead of one pair per lane: same results, the whole chip on the one pair.  "auto": try the
+    long kernels, stay on the batch kernels if they refuse the parameters."""
+    return "auto" if len(s1) * len(s2) >= LONG_MIN_CELLS and len(set(bytes(s2))) <= max_symbols else False
 
 
 def _run_batch(mode, s1s, s2s, a, gap_open, gap_extend, score_only=False, long=False, scale=1):
@@ -111,7 +117,13 @@ def _run_batch(mode, s1s, s2s, a, gap_open, gap_extend, score_only=False, long=F
         table = table * np.int32(scale)  # dyadic penalties: everything in units of 1 / scale
     pb = _native.PackedBatch(d1, o1, d2, o2, mode, table, code1, code2, gap_open, gap_extend,
                              gap_symbol=_gap(), flags=_native.SCORE_ONLY if score_only else 0)
-    scores, t1, t2, t_off, t_len = engine().batch(pb, long=long)
+    try:
+        scores, t1, t2, t_off, t_len = engine().batch(pb, long=long)
+    except _native.BioAlignError as e:
+        # a pair routed to the long kernels by its size alone that they do not take stays on the batch kernels
+        if not (long == "auto" and e.code == _native.EUNSUPPORTED):
+            raise
+        scores, t1, t2, t_off, t_len = engine().batch(pb, long=False)
     if score_only:
         return [int(x) for x in scores], None, None
     t1b, t2b = t1.tobytes(), t2.tobytes()
@@ -181,7 +193,7 @@ def AlignPair(mode: str, s1: bytes, s2: bytes, a, indelPenalty: int):
     """align_pair.go:3-21.  Unknown mode -> (-1, None, None)."""
     if mode not in _native.MODES:
         return -1, None, None
-    sc, t1, t2 = _run_batch(mode, [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty)
+    sc, t1, t2 = _run_batch(mode, [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty, long=_long_pair(s1, s2))
     return (sc[0],) + _trace_quirk(t1[0], t2[0])
 
 
@@ -191,13 +203,13 @@ def AlignGlobal(s1: bytes, s2: bytes, a, indelPenalty: int):
         # The reference's own traceback indexes s2[-1] here (stride 1 makes the two gap
         # deltas equal, align.go:128-130) and panics; keep the error behaviour.
         raise IndexError("index out of range [-1]")
-    sc, t1, t2 = _run_batch("global", [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty)
+    sc, t1, t2 = _run_batch("global", [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty, long=_long_pair(s1, s2))
     return sc[0], t1[0], t2[0]  # (align.go:126-143 appends every byte: no NUL quirk here)
 
 
 def AlignLocal(s1: bytes, s2: bytes, a, indelPenalty: int):
     """align.go:152-249."""
-    sc, t1, t2 = _run_batch("local", [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty)
+    sc, t1, t2 = _run_batch("local", [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty, long=_long_pair(s1, s2))
     return sc[0], t1[0], t2[0]
 
 
@@ -215,8 +227,7 @@ def AlignGlobalLS(s1: bytes, s2: bytes, a, indelPenalty: int):
     (panics, alternate tie-breaks); this one returns exactly AlignGlobal's result, which is what
     its author's disabled test asks for (align_test.go:55-66).  Pairs of LONG_MIN_CELLS cells
     or more go to the long-mode kernels when their parameters allow it."""
-    use_long = len(s1) * len(s2) >= LONG_MIN_CELLS and len(set(bytes(s2))) <= 100
-    sc, t1, t2 = _run_batch("global", [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty, long=use_long)
+    sc, t1, t2 = _run_batch("global", [bytes(s1)], [bytes(s2)], a, indelPenalty, indelPenalty, long=_long_pair(s1, s2))
     return sc[0], t1[0], t2[0]
 
 
@@ -253,7 +264,7 @@ def AlignGlobalAffine(s1: bytes, s2: bytes, a, gapOpenPenalty: float, gapExtendP
         raise ValueError("AlignGlobalAffine on the GPU path needs penalties that are multiples of 1/64 "
                          f"(got open {go!r}, extend {ge!r}): the kernels are exact integer Gotoh")
     # (a linear gap, open == extend, stays on the batch kernels: bioalign_long would take it for AlignPair's recurrence)
-    use_long = len(s1) * len(s2) >= LONG_MIN_CELLS and len(set(bytes(s2))) <= 64 and go != ge
+    use_long = _long_pair(s1, s2, 64) if go != ge else False
     sc, t1, t2 = _run_batch("global", [bytes(s1)], [bytes(s2)], a, int(go * scale), int(ge * scale), scale=scale,
                             long=use_long)
     return sc[0] / scale, t1[0], t2[0]

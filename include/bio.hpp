@@ -208,6 +208,45 @@ inline std::vector<Alignment> run(const std::string &mode, const std::vector<Seq
     }
     return res;
 }
+// pairs of 2^24 cells or more go to the intra-sequence kernels (bioalign_long) when their column alphabet allows it
+inline bool long_pair(const Seq &s1, const Seq &s2, int max_symbols)
+{
+    if ((unsigned long long)s1.size() * s2.size() < (1ull << 24)) return false;
+    std::array<bool, 256> seen{};
+    int distinct = 0;
+    for (unsigned char b : s2) distinct += !seen[b], seen[b] = true;
+    return distinct <= max_symbols;
+}
+// one pair; `try_long`: on the long kernels if they take the parameters, else on the batch kernels
+inline Alignment run1(const std::string &mode, const Seq &s1, const Seq &s2, const Aligner &a, int go, int ge, bool try_long)
+{
+    if (try_long) {
+        try {
+            return run(mode, {s1}, {s2}, a, go, ge, true)[0];
+        } catch (const Error &e) {
+            if (e.code != BIOALIGN_EUNSUPPORTED) throw;
+        }
+    }
+    return run(mode, {s1}, {s2}, a, go, ge, false)[0];
+}
+// AlignPair's trace() (align_pair.go:197-216): a symbol 0 is not appended to its trace, and the reversal loop runs over
+// len(t1)/2 indexing both traces with len(t1)-1 -- reproduced on the aligned traces the kernels return, only when one
+// of them holds a 0 byte (a NUL in a sequence, or a GapSymbol of 0)
+inline void trace_quirk(Alignment &r)
+{
+    if (r.t1.find('\0') == std::string::npos && r.t2.find('\0') == std::string::npos) return;
+    std::string r1, r2;
+    for (auto it = r.t1.rbegin(); it != r.t1.rend(); ++it) if (*it) r1 += *it;
+    for (auto it = r.t2.rbegin(); it != r.t2.rend(); ++it) if (*it) r2 += *it;
+    const size_t last = r1.size() - 1;
+    for (size_t i = 0; i < r1.size() / 2; ++i) {
+        std::swap(r1[i], r1[last - i]);
+        if (last - i >= r2.size()) throw std::out_of_range("index out of range (align_pair.go:213)");  // the reference panics
+        std::swap(r2[i], r2[last - i]);
+    }
+    r.t1 = r1;
+    r.t2 = r2;
+}
 }  // namespace detail
 
 // additive batch entry points
@@ -223,31 +262,29 @@ inline std::vector<Alignment> AlignAffineBatch(const std::string &mode, const st
 }
 
 inline Alignment AlignPair(const std::string &mode, const Seq &s1, const Seq &s2, const Aligner &a, int indelPenalty)
-{  // align_pair.go:3-21
-    return detail::run(mode, {s1}, {s2}, a, indelPenalty, indelPenalty, false)[0];
+{  // align_pair.go:3-21 (long pairs: the intra-sequence kernels, same result)
+    Alignment r = detail::run1(mode, s1, s2, a, indelPenalty, indelPenalty, detail::long_pair(s1, s2, 100));
+    detail::trace_quirk(r);
+    return r;
 }
 inline Alignment AlignPairLong(const std::string &mode, const Seq &s1, const Seq &s2, const Aligner &a, int indelPenalty)
 {  // AlignPair for one long pair: the intra-sequence wavefront kernels (bioalign_long)
-    return detail::run(mode, {s1}, {s2}, a, indelPenalty, indelPenalty, true)[0];
+    Alignment r = detail::run(mode, {s1}, {s2}, a, indelPenalty, indelPenalty, true)[0];
+    detail::trace_quirk(r);
+    return r;
 }
 inline Alignment AlignGlobal(const Seq &s1, const Seq &s2, const Aligner &a, int indelPenalty)
 {  // align.go:76-145; with an empty s2 the reference indexes s2[-1] (align.go:128-130) and panics
     if (s2.empty() && !s1.empty()) throw std::out_of_range("index out of range [-1]");
-    return AlignPair("global", s1, s2, a, indelPenalty);
+    return detail::run1("global", s1, s2, a, indelPenalty, indelPenalty, detail::long_pair(s1, s2, 100));
 }
 inline Alignment AlignLocal(const Seq &s1, const Seq &s2, const Aligner &a, int indelPenalty)
 {  // align.go:152-249
-    return AlignPair("local", s1, s2, a, indelPenalty);
+    return detail::run1("local", s1, s2, a, indelPenalty, indelPenalty, detail::long_pair(s1, s2, 100));
 }
 inline Alignment AlignGlobalLS(const Seq &s1, const Seq &s2, const Aligner &a, int indelPenalty)
 {  // align_linear.go:9-45: AlignGlobal's result (align_test.go:55-66); long inputs take the long-mode kernels
-    if ((unsigned long long)s1.size() * s2.size() >= (1ull << 24)) {
-        std::array<bool, 256> seen{};
-        int distinct = 0;
-        for (unsigned char b : s2) distinct += !seen[b], seen[b] = true;
-        if (distinct <= 4) return AlignPairLong("global", s1, s2, a, indelPenalty);
-    }
-    return AlignPair("global", s1, s2, a, indelPenalty);
+    return detail::run1("global", s1, s2, a, indelPenalty, indelPenalty, detail::long_pair(s1, s2, 100));
 }
 inline std::tuple<double, Seq, Seq> AlignGlobalAffine(const Seq &s1, const Seq &s2, const Aligner &a, double gapOpenPenalty,
                                                       double gapExtendPenalty)
@@ -268,7 +305,8 @@ inline std::tuple<double, Seq, Seq> AlignGlobalAffine(const Seq &s1, const Seq &
         Scaled(const Aligner &a_, int k_) : a(a_), k(k_) {}
         int Score(uint8_t x, uint8_t y) const override { return k * a.Score(x, y); }
     } scaled(a, scale);
-    Alignment r = detail::run("global", {s1}, {s2}, scaled, (int)(gapOpenPenalty * scale), (int)(gapExtendPenalty * scale), false)[0];
+    const bool lng = gapOpenPenalty != gapExtendPenalty && detail::long_pair(s1, s2, 64);
+    Alignment r = detail::run1("global", s1, s2, scaled, (int)(gapOpenPenalty * scale), (int)(gapExtendPenalty * scale), lng);
     return {(double)r.score / scale, r.t1, r.t2};
 }
 

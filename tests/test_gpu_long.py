@@ -92,6 +92,20 @@ def test_long_several_strips_and_align_global_ls():
     assert bio_amd.LinearGap(got[1], got[2], a, 1) == got[0]
 
 
+def test_single_pair_entry_points_route_long_pairs():
+    # AlignGlobal / AlignLocal / AlignPair of 2^24 cells or more run on the long kernels (same results); a pair they
+    # refuse for its parameters stays on the batch kernels
+    a, oa = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
+    x, y = _pair(4200, 4100, 91)
+    assert bio_amd.align._long_pair(x, y) == "auto"
+    assert bio_amd.AlignGlobal(x, y, a, 1) == O.AlignGlobal(x, y, oa, 1)
+    assert bio_amd.AlignLocal(x, y, a, 1) == O.AlignLocal(x, y, oa, 1)
+    assert bio_amd.AlignPair("fitting", x, y, a, 1) == O.AlignPair("fitting", x, y, oa, 1)
+    big = bio_amd.MatchAligner(100, -100)  # the long kernels refuse these scores, the call falls back to the batch
+    with pytest.raises(bio_amd._native.BioAlignError):  # kernels, and their refusal is the error that reaches the caller
+        bio_amd.AlignGlobal(x, y, big, 20)
+
+
 def test_long_unsupported_fails_loudly():
     # what the long kernels do not cover is refused, not computed some other way: more than 64 column symbols, and
     # gap penalties with open < extend
