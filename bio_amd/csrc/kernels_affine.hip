@@ -19,9 +19,17 @@
 // (the profile byte holds w + 2*ext + c so that the diagonal add works on hq directly).
 // The true zero of local mode is ext*(i+j) in this space: wave-uniform, an SGPR operand.
 //
-// Traceback matrix: four decision bits per cell, each the sign bit of one subtraction,
-// shifted into a bit plane with one v_alignbit_b32:
+// Traceback matrix: four decision bits per cell, each a comparison a > b of two scores that
+// can only be a >= b:
 //   nF = [F' != H']   nD = [diag + w != H']   oE = [E' opened from H]   oF = [F' opened from H]
+// On gfx950 a sign push (v_sub_u32 + v_alignbit_b32) costs three issue units, the alignbit being
+// half-rate.  The scores therefore live as the BIT PATTERNS OF FLOATS: x is kept as
+// 0x4B400000 + x, which read as an f32 is exactly 2^23 + 2^22 + x for |x| < 2^22 (the planner
+// proves that range).  Integer adds and maxima work on the patterns unchanged, and
+//   bit = v_sub_f32(a, b) clamp      (1.0 if a > b, 0.0 if a == b: the clamp saturates at 1)
+//   plane = v_fma_f32(plane, 2.0, bit)
+// are two full-rate instructions.  A plane starts at 2^7, so after the 16 rows of a column its
+// pattern is 0x4B000000 | the 16 bits, which one v_perm_b32 moves into the decision word.
 // Middle-level back-pointer = G2 (close the gap in s2) if !nF, else diagonal if !nD, else
 // G1 -- exactly the candidate order above.  (Local: a cell whose true score is 0 is a
 // skip-prefix cell whatever its bits say; the traceback tracks the true score.)
@@ -33,15 +41,23 @@
 #include "common.h"
 #include "device_helpers.h"
 
-#define BA_NEG (-(1 << 28))  // minus infinity of the E / F levels (align_affine.go:36-37, 45-46, 63-64)
+#define BA_FBIAS 0x4B400000  // score x is held as BA_FBIAS + x: the f32 with this pattern is 2^23 + 2^22 + x
+#define BA_NEG (BA_FBIAS - (1 << 22))  // minus infinity of the E / F levels (align_affine.go:36-37, 45-46, 63-64): below every score the planner admits
 #ifndef BA_AFF_WPE
 #define BA_AFF_WPE 1  // wavefronts per SIMD the register allocator is asked to leave room for
 #endif
 
-// push the sign bit of t into the bottom of a bit plane
-__device__ __forceinline__ uint32_t ba_push_sign(uint32_t acc, int t)
+// 1.0f if a > b, 0.0f if a == b (a >= b; both are score patterns, see the header)
+__device__ __forceinline__ float ba_gt_bit(int a, int b)
 {
-    return __builtin_amdgcn_alignbit(acc, (uint32_t)t, 31);
+    float r;
+    asm("v_sub_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// 16 decision bits gathered in a float plane (pattern 0x4B000000 | bits) go into the bottom of a decision word
+__device__ __forceinline__ uint32_t ba_push16(uint32_t acc, float plane)
+{
+    return __builtin_amdgcn_perm(acc, __float_as_uint(plane), 0x05040100u);
 }
 
 // One column of one strip.  `top_hq`/`f` enter as hq and F' of the row above the strip.
@@ -60,13 +76,12 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
     int up = top_hq, diag = topdiag;
     topdiag = top_hq;
     int kprev = 0;
+    float pl[4];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int eo = e[r];
         const int en = max(eo, hq[r]);
-        acc[2] = ba_push_sign(acc[2], eo - en);
         const int fn = max(f, up);
-        acc[3] = ba_push_sign(acc[3], f - fn);
         const int d = NIB ? diag + (int)__builtin_amdgcn_ubfe(pw[NIB ? r >> 3 : 0], 4 * (r & 7), 4) + kappa
                           : diag + ba_sbyte(pw[NIB ? 0 : r >> 2], r & 3);
         int H = ba_max3(en, fn, d);
@@ -74,8 +89,22 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
             fl += ge;  // zero level of row r: ext*(i+j)
             H = max(H, fl);
         }
-        acc[0] = ba_push_sign(acc[0], fn - H);
-        acc[1] = ba_push_sign(acc[1], d - H);
+        const float b0 = ba_gt_bit(H, fn), b1 = ba_gt_bit(H, d), b2 = ba_gt_bit(en, eo), b3 = ba_gt_bit(fn, f);
+        if ((r & 15) == 0) {  // 2^7 * 2 + bit
+            pl[0] = b0 + 256.0f;
+            pl[1] = b1 + 256.0f;
+            pl[2] = b2 + 256.0f;
+            pl[3] = b3 + 256.0f;
+        } else {
+            pl[0] = __builtin_fmaf(pl[0], 2.0f, b0);
+            pl[1] = __builtin_fmaf(pl[1], 2.0f, b1);
+            pl[2] = __builtin_fmaf(pl[2], 2.0f, b2);
+            pl[3] = __builtin_fmaf(pl[3], 2.0f, b3);
+        }
+        if ((r & 15) == 15) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = ba_push16(acc[k], pl[k]);
+        }
         if (MODE == BA_LOCAL) {
             const int key = (int)(((uint32_t)(H - fl) << key_shift) + (uint32_t)((r & 1) ? klow1 : klow0));
             if (r & 1)
@@ -161,8 +190,9 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, BA_AFF_WPE) ba_dp_affine_ker
     const int jmax = (1 << jbits) - 1;
 
     // H'(i, 0) and H'(0, j): align_pair.go:110-113, 130-131, 158-159, 187-188 on the middle level
-    auto col0 = [&](int i) { return left_free ? ge * max(i, 0) : (i >= 1 ? -c : 0); };
-    auto row0 = [&](int j) { return top_free ? ge * j : (j >= 1 ? -c : 0); };
+    // (all scores as float patterns: + BA_FBIAS)
+    auto col0 = [&](int i) { return BA_FBIAS + (left_free ? ge * max(i, 0) : (i >= 1 ? -c : 0)); };
+    auto row0 = [&](int j) { return BA_FBIAS + (top_free ? ge * j : (j >= 1 ? -c : 0)); };
 
     int best_sc = 0, best_i = 0, best_j = 0;
     if (MODE == BA_GLOBAL) {  // strips == 0: the end cell is (0, m) on the top border
@@ -268,7 +298,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, BA_AFF_WPE) ba_dp_affine_ker
                     // the row above the strip: row 0 (F = -inf, align_affine.go:63-64) or the previous strip's last row
                     const int top_hq = (s == 0) ? row0(j) - c : in.b[q].x;
                     int f = (s == 0) ? BA_NEG : in.b[q].y;
-                    int fl0 = ge * (i0 + j);  // local: zero level of the row above the strip
+                    int fl0 = BA_FBIAS + ge * (i0 + j);  // local: zero level of the row above the strip
                     if (MODE == BA_LOCAL) asm volatile("v_mov_b32 %0, %1" : "=v"(fl0) : "s"(fl0));  // a per-lane chain, not 32 scalars
                     ba_affine_column<MODE, R, NIB>(hq, e, acc, rkey, pw, top_hq, f, topdiag, c, ge, fl0, key_shift,
                                                    (1 << jbits) + (jmax - j), jmax - j, kappa);
@@ -315,7 +345,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, BA_AFF_WPE) ba_dp_affine_ker
                 }
             }
             // true score of the end cell: H = hq + c - ext*(i+j)
-            best_sc = ecur + c - ge * (n + ej);
+            best_sc = ecur - BA_FBIAS + c - ge * (n + ej);
             best_i = n;
             best_j = ej;
         }
