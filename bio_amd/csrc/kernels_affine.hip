@@ -80,15 +80,15 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int eo = e[r];
-        const int en = max(eo, hq[r]);
+        // Local: the zero level of row r, ext*(i+j), enters through E' -- en = max(E', zero) never decides anything it
+        // should not: a gap level is only looked at by a traceback that came from a cell above its zero level, and
+        // E' of every cell of that gap is then above the (lower or equal) zero levels to its left.
+        if (MODE == BA_LOCAL) fl += ge;
+        const int en = MODE == BA_LOCAL ? ba_max3(eo, hq[r], fl) : max(eo, hq[r]);
         const int fn = max(f, up);
         const int d = NIB ? diag + (int)__builtin_amdgcn_ubfe(pw[NIB ? r >> 3 : 0], 4 * (r & 7), 4) + kappa
                           : diag + ba_sbyte(pw[NIB ? 0 : r >> 2], r & 3);
-        int H = ba_max3(en, fn, d);
-        if (MODE == BA_LOCAL) {
-            fl += ge;  // zero level of row r: ext*(i+j)
-            H = max(H, fl);
-        }
+        const int H = ba_max3(en, fn, d);
         const float b0 = ba_gt_bit(H, fn), b1 = ba_gt_bit(H, d), b2 = ba_gt_bit(en, eo), b3 = ba_gt_bit(fn, f);
         if ((r & 15) == 0) {  // 2^7 * 2 + bit
             pl[0] = b0 + 256.0f;
