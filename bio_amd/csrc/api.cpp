@@ -175,6 +175,7 @@ struct bioalign_plan {
     int pipe = 0;  // affine: one block per bundle, strips pipelined over its waves (kernels_affine.hip)
     int K = 2;  // residue bits per cell in the traceback matrix
     int nib = 0, kappa = 0;  // affine, large alphabets: 4-bit strip profile (kernels_affine.hip)
+    int fkey = 0;            // affine local: float-built best-cell keys (kernels_affine.hip)
     uint64_t cells = 0;
     std::vector<BaBundle> bundles;
     std::vector<Chunk> chunks;
@@ -453,6 +454,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         const int key_shift = bit_length(max_m | 1) + 1;
         if (pl->mode == BIOALIGN_LOCAL && (min_nm_max + 1) * (uint64_t)std::max(wmax, 1) >= (1ull << (31 - key_shift)))
             return ctx->fail(BIOALIGN_EUNSUPPORTED, "local affine scores do not fit the position key");
+        pl->fkey = pl->mode == BIOALIGN_LOCAL && (min_nm_max + 2) * (uint64_t)std::max(wmax, 1) < (1ull << (24 - std::min(key_shift, 24)));
         if (pl->gap_open > 127)
             return ctx->fail(BIOALIGN_EUNSUPPORTED, "gap_open %d does not fit the int8 profile", pl->gap_open);
         pl->K = 0;
@@ -608,6 +610,10 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         pl->pipe = strips_max >= 2 && pl->bundles.size() < pipe_below;
         if (pl->pipe) {
             pl->waves = std::min(8, std::max(2, strips_max));
+            // the waves of a block take strips w, w + W, ...: seven waves when that leaves fewer of them idle in the last
+            // round than eight (19 strips: 7 + 7 + 5 instead of 8 + 8 + 3; config 3 1969 -> 2032 GCUPS)
+            if (strips_max > 8 && (strips_max + 6) / 7 * 7 < (strips_max + 7) / 8 * 8) pl->waves = 7;
+            if (const uint64_t w = env_u64("BIOALIGN_PIPE_WAVES", 0)) pl->waves = (int)std::min<uint64_t>(std::max<uint64_t>(w, 2), 8);
             while (pl->waves > 2 && ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, pl->waves, pl->nib) > 80 * 1024)
                 --pl->waves;
             if ((max_m + 3) / 4 >= 65536) pl->pipe = 0;  // progress word: 16 bits of column groups
@@ -770,6 +776,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             dp.gap_ext = pl->gap_ext;
             dp.nib = pl->nib;
             dp.kappa = pl->kappa;
+            dp.fkey = pl->fkey;
             const bool timed = pl->ev_used < pl->ev0.size();
             if (timed) HIP_TRY(ctx, hipEventRecord(pl->ev0[pl->ev_used], st));
             if (pl->affine)

@@ -67,7 +67,10 @@ __device__ __forceinline__ uint32_t ba_push16(uint32_t acc, float plane)
 // so the largest key of a row pair is its best cell, first in row-major order.
 // (klow0 / klow1: the low key bits for the even / odd rows of this column.)
 // NIB: pw holds 4-bit scores (row r = nibble r); the diagonal is hq + nibble + kappa (v_bfe_u32 + v_add3_u32).
-template <int MODE, int R, bool NIB>
+// FKEY (local): the key is built as a float -- v_sub_f32 + v_fma_f32, full-rate, instead of a subtract and a half-rate
+// v_lshl_add -- when (score + 1) << key_shift stays below 2^24 (the planner decides); keys are non-negative floats, whose
+// patterns order like integers.
+template <int MODE, int R, bool NIB, bool FKEY>
 __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint32_t (&acc)[4], int (&rkey)[R / 2],
                                                  const uint32_t (&pw)[NIB ? R / 8 : R / 4], int top_hq, int &f,
                                                  int &topdiag, int c, int ge, int fl, int key_shift, int klow0,
@@ -77,6 +80,7 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
     topdiag = top_hq;
     int kprev = 0;
     float pl[4];
+    const float kscale = (float)(1 << key_shift), klow0f = (float)klow0, klow1f = (float)klow1;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int eo = e[r];
@@ -106,7 +110,14 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
             for (int k = 0; k < 4; ++k) acc[k] = ba_push16(acc[k], pl[k]);
         }
         if (MODE == BA_LOCAL) {
-            const int key = (int)(((uint32_t)(H - fl) << key_shift) + (uint32_t)((r & 1) ? klow1 : klow0));
+            int key;
+            if (FKEY) {
+                // (volatile: left to itself the scheduler gathers these at the end of the column and runs out of registers)
+                float sc;
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(sc) : "v"(H), "v"(fl));
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(key) : "v"(sc), "v"(kscale), "v"((r & 1) ? klow1f : klow0f));
+            } else
+                key = (int)(((uint32_t)(H - fl) << key_shift) + (uint32_t)((r & 1) ? klow1 : klow0));
             if (r & 1)
                 rkey[r / 2] = ba_max3(rkey[r / 2], kprev, key);
             else
@@ -137,8 +148,8 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
 //
 // NIB: 4-bit strip profile (scores w - min(w), top-free modes, R == 16): an alphabet of 20 column symbols
 // takes 10 KB of LDS per wavefront instead of 20, which doubles the wavefronts a CU holds.
-template <int MODE, int R, bool PIPE, bool NIB>
-__global__ void __launch_bounds__(PIPE ? 512 : 256, BA_AFF_WPE) ba_dp_affine_kernel(BaDpParams P)
+template <int MODE, int R, bool PIPE, bool NIB, bool FKEY = false>
+__global__ void __launch_bounds__(PIPE ? 512 : 256, R == 16 ? 4 : BA_AFF_WPE) ba_dp_affine_kernel(BaDpParams P)
 {
     extern __shared__ __align__(16) uint32_t lds[];
     constexpr int HALVES = R / 16;
@@ -300,7 +311,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, BA_AFF_WPE) ba_dp_affine_ker
                     int f = (s == 0) ? BA_NEG : in.b[q].y;
                     int fl0 = BA_FBIAS + ge * (i0 + j);  // local: zero level of the row above the strip
                     if (MODE == BA_LOCAL) asm volatile("v_mov_b32 %0, %1" : "=v"(fl0) : "s"(fl0));  // a per-lane chain, not 32 scalars
-                    ba_affine_column<MODE, R, NIB>(hq, e, acc, rkey, pw, top_hq, f, topdiag, c, ge, fl0, key_shift,
+                    ba_affine_column<MODE, R, NIB, FKEY>(hq, e, acc, rkey, pw, top_hq, f, topdiag, c, ge, fl0, key_shift,
                                                    (1 << jbits) + (jmax - j), jmax - j, kappa);
                     if ((j - 1) % CPW == CPW - 1)
                         dirs[(size_t)((j - 1) / CPW) * 64] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
@@ -354,7 +365,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, BA_AFF_WPE) ba_dp_affine_ker
             // Row pairs that lie wholly above the matrix (first strip) carry no scores.
 #pragma unroll
             for (int r = 0; r < R; r += 2) {
-                const int k = rkey[r / 2];
+                const int k = FKEY ? (int)__int_as_float(rkey[r / 2]) : rkey[r / 2];
                 const int sc = k >> key_shift;
                 if (i0 + r + 2 >= 1 && sc > best_sc) {
                     best_sc = sc;
@@ -600,22 +611,42 @@ static hipError_t launch_dp_aff(const BaDpParams &P, int waves, int pipe, hipStr
         // the 4-bit profile exists for the modes with a free top row and 16-row strips (api.cpp picks it)
         if constexpr (R == 16 && (MODE == BA_LOCAL || MODE == BA_FITTING)) {
             if (pipe) {
+                if (MODE == BA_LOCAL && P.fkey) {
+                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, true, true, MODE == BA_LOCAL>)) != hipSuccess) return ae;
+                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true, true, MODE == BA_LOCAL>), grid, block, lds, st, P);
+            } else {
                 if ((ae = allow(&ba_dp_affine_kernel<MODE, R, true, true>)) != hipSuccess) return ae;
                 hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true, true>), grid, block, lds, st, P);
+            }
+            } else {
+                if (MODE == BA_LOCAL && P.fkey) {
+                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, false, true, MODE == BA_LOCAL>)) != hipSuccess) return ae;
+                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false, true, MODE == BA_LOCAL>), grid, block, lds, st, P);
             } else {
                 if ((ae = allow(&ba_dp_affine_kernel<MODE, R, false, true>)) != hipSuccess) return ae;
                 hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false, true>), grid, block, lds, st, P);
+            }
             }
             return hipGetLastError();
         }
         return hipErrorInvalidValue;
     }
     if (pipe) {
-        if ((ae = allow(&ba_dp_affine_kernel<MODE, R, true, false>)) != hipSuccess) return ae;
-        hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true, false>), grid, block, lds, st, P);
+        if (MODE == BA_LOCAL && P.fkey) {
+                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, true, false, MODE == BA_LOCAL>)) != hipSuccess) return ae;
+                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true, false, MODE == BA_LOCAL>), grid, block, lds, st, P);
+            } else {
+                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, true, false>)) != hipSuccess) return ae;
+                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true, false>), grid, block, lds, st, P);
+            }
     } else {
-        if ((ae = allow(&ba_dp_affine_kernel<MODE, R, false, false>)) != hipSuccess) return ae;
-        hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false, false>), grid, block, lds, st, P);
+        if (MODE == BA_LOCAL && P.fkey) {
+                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, false, false, MODE == BA_LOCAL>)) != hipSuccess) return ae;
+                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false, false, MODE == BA_LOCAL>), grid, block, lds, st, P);
+            } else {
+                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, false, false>)) != hipSuccess) return ae;
+                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false, false>), grid, block, lds, st, P);
+            }
     }
     return hipGetLastError();
 }

@@ -95,6 +95,19 @@ def test_affine_protein(mode):
     _check_affine(mode, s1s, s2s, bio_amd.Blosum62, O.Blosum62(), 11, 1)
 
 
+def test_affine_local_best_cell_keys_int_and_float():
+    # The local kernels find the first best cell through a packed key, built as a float when (score + 1) << key_shift
+    # stays below 2^24 and in integers otherwise (kernels_affine.hip, FKEY): the same pairs with small scores (float
+    # keys) and with scores 30 times as large (integer keys: 302 * 60 >= 2^(24 - 10)); many equal maxima (repeats).
+    rng = random.Random(23)
+    s1s = [bytes(rng.choice(b"ACGT") for _ in range(rng.choice([300, 290, 64]))) for _ in range(70)]
+    s2s = [bytes(x[k] if rng.random() < 0.8 else rng.choice(b"ACGT") for k in range(len(x))) + b"ACGT" * 3 for x in s1s]
+    s1s += [b"ACGTACGTAC" * 30] * 6
+    s2s += [b"GTACGTAC" * 37] * 6
+    _check_affine("local", s1s, s2s, bio_amd.MatchAligner(2, -3), O.MatchAligner(2, -3), 5, 2)
+    _check_affine("local", s1s, s2s, bio_amd.MatchAligner(60, -60), O.MatchAligner(60, -60), 40, 20)
+
+
 def test_affine_fitting_reads_against_windows():
     # config-4 shape scaled down: read = s1, window = s2
     s1, o1, s2, o2 = synth.fitting_reads(70, 60, 400, config=4)
