@@ -606,49 +606,26 @@ static hipError_t launch_dp_aff(const BaDpParams &P, int waves, int pipe, hipStr
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                                : hipSuccess;
     };
-    hipError_t ae = hipSuccess;
+    // local mode has a second instantiation whose best-cell keys are built as floats (FKEY)
+    auto go = [&](auto pipe_c, auto nib_c) {
+        constexpr bool PIPE = decltype(pipe_c)::value, NIB = decltype(nib_c)::value;
+        hipError_t ae;
+        if (MODE == BA_LOCAL && P.fkey) {
+            if ((ae = allow(&ba_dp_affine_kernel<MODE, R, PIPE, NIB, MODE == BA_LOCAL>)) != hipSuccess) return ae;
+            hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, PIPE, NIB, MODE == BA_LOCAL>), grid, block, lds, st, P);
+        } else {
+            if ((ae = allow(&ba_dp_affine_kernel<MODE, R, PIPE, NIB>)) != hipSuccess) return ae;
+            hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, PIPE, NIB>), grid, block, lds, st, P);
+        }
+        return hipGetLastError();
+    };
     if (P.nib) {
         // the 4-bit profile exists for the modes with a free top row and 16-row strips (api.cpp picks it)
-        if constexpr (R == 16 && (MODE == BA_LOCAL || MODE == BA_FITTING)) {
-            if (pipe) {
-                if (MODE == BA_LOCAL && P.fkey) {
-                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, true, true, MODE == BA_LOCAL>)) != hipSuccess) return ae;
-                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true, true, MODE == BA_LOCAL>), grid, block, lds, st, P);
-            } else {
-                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, true, true>)) != hipSuccess) return ae;
-                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true, true>), grid, block, lds, st, P);
-            }
-            } else {
-                if (MODE == BA_LOCAL && P.fkey) {
-                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, false, true, MODE == BA_LOCAL>)) != hipSuccess) return ae;
-                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false, true, MODE == BA_LOCAL>), grid, block, lds, st, P);
-            } else {
-                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, false, true>)) != hipSuccess) return ae;
-                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false, true>), grid, block, lds, st, P);
-            }
-            }
-            return hipGetLastError();
-        }
+        if constexpr (R == 16 && (MODE == BA_LOCAL || MODE == BA_FITTING))
+            return pipe ? go(std::true_type{}, std::true_type{}) : go(std::false_type{}, std::true_type{});
         return hipErrorInvalidValue;
     }
-    if (pipe) {
-        if (MODE == BA_LOCAL && P.fkey) {
-                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, true, false, MODE == BA_LOCAL>)) != hipSuccess) return ae;
-                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true, false, MODE == BA_LOCAL>), grid, block, lds, st, P);
-            } else {
-                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, true, false>)) != hipSuccess) return ae;
-                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, true, false>), grid, block, lds, st, P);
-            }
-    } else {
-        if (MODE == BA_LOCAL && P.fkey) {
-                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, false, false, MODE == BA_LOCAL>)) != hipSuccess) return ae;
-                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false, false, MODE == BA_LOCAL>), grid, block, lds, st, P);
-            } else {
-                if ((ae = allow(&ba_dp_affine_kernel<MODE, R, false, false>)) != hipSuccess) return ae;
-                hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, false, false>), grid, block, lds, st, P);
-            }
-    }
-    return hipGetLastError();
+    return pipe ? go(std::true_type{}, std::false_type{}) : go(std::false_type{}, std::false_type{});
 }
 
 template <int MODE>
