@@ -108,6 +108,24 @@ def test_affine_local_best_cell_keys_int_and_float():
     _check_affine("local", s1s, s2s, bio_amd.MatchAligner(60, -60), O.MatchAligner(60, -60), 40, 20)
 
 
+@pytest.mark.parametrize("mode", ["global", "local"])
+def test_affine_scores_near_the_float_pattern_range(mode):
+    # The kernels hold a score x as the float pattern 0x4B400000 + x, exact for |x| < 2^22, and the planner admits pairs
+    # with (n + m + 2) * (128 + open + extend) < 2^22.  7900 x 8000 with extend 60 puts the working scores near a million
+    # (bias 60 * (i + j)) and the global score far below zero; bit-exact against the oracle all the same.
+    rng = random.Random(404)
+    x = bytes(rng.choice(b"ACGT") for _ in range(7900))
+    y = bytes(rng.choice(b"ACGT") for _ in range(8000))
+    pa, oa = bio_amd.MatchAligner(6, -127), O.MatchAligner(6, -127)
+    scores, t1s, t2s = bio_amd.AlignAffineBatch(mode, [x, b"ACGTTGCA"], [y, b"ACGTGCA"], pa, 61, 60)
+    for p, (a, b) in enumerate([(x, y), (b"ACGTTGCA", b"ACGTGCA")]):
+        assert (scores[p], t1s[p], t2s[p]) == O.AlignAffine(mode, a, b, oa, 61, 60), (mode, p)
+    if mode == "global":
+        assert scores[0] < -200000
+    with pytest.raises(bio_amd._native.BioAlignError):  # one step past the planner's bound
+        bio_amd.AlignAffineBatch(mode, [x + x + x], [y + y + y], pa, 61, 60)
+
+
 def test_affine_fitting_reads_against_windows():
     # config-4 shape scaled down: read = s1, window = s2
     s1, o1, s2, o2 = synth.fitting_reads(70, 60, 400, config=4)
