@@ -47,6 +47,15 @@
 #define BA_AFF_WPE 1  // wavefronts per SIMD the register allocator is asked to leave room for
 #endif
 
+// Signed byte k of w through v_bfe_i32, kept out of the compiler's hands: it would fold the extraction into
+// v_add_u32_sdwa, and among the full-rate float instructions of this cell an SDWA add stalls the pipeline far beyond
+// its own half-rate slot (config 4: 2562 -> 2923 GCUPS with one instruction more per cell).
+__device__ __forceinline__ int ba_sbyte_bfe(uint32_t w, int k)
+{
+    int r = __builtin_amdgcn_sbfe(w, 8 * k, 8);
+    asm("" : "+v"(r));
+    return r;
+}
 // 1.0f if a > b, 0.0f if a == b (a >= b; both are score patterns, see the header)
 __device__ __forceinline__ float ba_gt_bit(int a, int b)
 {
@@ -91,7 +100,7 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
         const int en = MODE == BA_LOCAL ? ba_max3(eo, hq[r], fl) : max(eo, hq[r]);
         const int fn = max(f, up);
         const int d = NIB ? diag + (int)__builtin_amdgcn_ubfe(pw[NIB ? r >> 3 : 0], 4 * (r & 7), 4) + kappa
-                          : diag + ba_sbyte(pw[NIB ? 0 : r >> 2], r & 3);
+                          : diag + ba_sbyte_bfe(pw[NIB ? 0 : r >> 2], r & 3);
         const int H = ba_max3(en, fn, d);
         const float b0 = ba_gt_bit(H, fn), b1 = ba_gt_bit(H, d), b2 = ba_gt_bit(en, eo), b3 = ba_gt_bit(fn, f);
         if ((r & 15) == 0) {  // 2^7 * 2 + bit
