@@ -13,13 +13,16 @@ constexpr int ITERS = 2048;
 constexpr int CH = 16;
 
 #define OPK(str) asm volatile(str : "+v"(a[k]) : "v"(b[k]), "v"(c[k]) : "vcc")
+#define OPK2(str) asm volatile(str : "+v"(a[k]), "+v"(c[k]) : "v"(b[k]) : "vcc")  // %0 = a, %1 = c (both read and written), %2 = b
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int OP>
 __global__ void __launch_bounds__(256) op_kernel(int *out, int seed, unsigned long long *clk)
 {
     int a[CH], b[CH], c[CH];
+    v2f p2[CH], q2[CH];
 #pragma unroll
-    for (int k = 0; k < CH; ++k) { a[k] = seed + threadIdx.x + k; b[k] = seed * 3 + k; c[k] = seed ^ k; }
+    for (int k = 0; k < CH; ++k) { a[k] = seed + threadIdx.x + k; b[k] = seed * 3 + k; c[k] = seed ^ k; p2[k] = {(float)(seed + k), 1.0f}; q2[k] = {0.5f, (float)k}; }
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
@@ -88,12 +91,21 @@ __global__ void __launch_bounds__(256) op_kernel(int *out, int seed, unsigned lo
             if (OP == 61) OPK("v_add_co_u32 %0, vcc, %0, %1");
             if (OP == 62) OPK("v_sub_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2");
             if (OP == 63) OPK("v_mad_i32_i24 %0, %0, %1, %2");
+            // round 2, float-pattern decision bits of the affine cell (kernels_affine.hip)
+            if (OP == 64) OPK("v_sub_f32_e64 %0, %0, %1 clamp");
+            if (OP == 65) OPK("v_fmac_f32 %0, 2.0, %1");
+            if (OP == 66) asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1] clamp" : "+v"(p2[k]) : "v"(q2[k]));
+            if (OP == 67) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p2[k]) : "v"(q2[k]));
+            if (OP == 68) OPK2("v_add_u32_sdwa %0, sext(%2), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\tv_fmac_f32 %1, 2.0, %2");
+            if (OP == 69) OPK2("v_bfe_i32 %1, %2, 8, 8\n\tv_add_u32 %0, %0, %1\n\tv_fmac_f32 %1, 2.0, %2");
+            if (OP == 70) OPK2("v_add_u32_sdwa %0, sext(%2), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\tv_max_i32 %1, %1, %2");
+            if (OP == 71) OPK2("v_sub_f32_e64 %1, %0, %2 clamp\n\tv_fmac_f32 %0, 2.0, %1");
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     int r = 0;
 #pragma unroll
-    for (int k = 0; k < CH; ++k) r += a[k];
+    for (int k = 0; k < CH; ++k) r += a[k] + c[k] + (int)p2[k].x + (int)p2[k].y;
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
     if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
@@ -103,7 +115,8 @@ static const char *NAMES[] = {"v_add_u32", "v_max_i32", "v_max3_i32", "v_cmp_gt_
     "v_lshl_add_u32", "v_and_b32", "v_max_u32", "v_sub_u32", "v_add3_u32", "v_max_i16", "v_bfe_i32", "v_mov_b32",
     "v_alignbit_b32", "v_fma_f32", "v_pk_max_f16", "v_subb_co_u32", "v_med3_i32", "v_pk_sub_i16", "v_perm_b32", "v_max_f16",
     "v_cmp_gt_i32+v_addc_co_u32 (pair)", "v_xor_b32", "v_min_i32",
-    "v_dot4_i32_i8", "v_dot4c_i32_i8", "v_sub_co_u32", "v_add_u16", "v_sub_u16", "v_max_u16", "v_min_i16", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_or_b32", "v_lshl_or_b32", "v_and_or_b32", "v_bfi_b32", "v_sub_u32 clamp", "v_mad_u32_u24", "v_mul_u32_u24", "v_mad_u16", "v_alignbyte_b32", "v_add_u16_sdwa(sext byte)", "v_max_i16_sdwa(word1)", "v_add_u32 dpp wave_shr", "v_mov_b32 dpp wave_shr", "v_bcnt_u32_b32", "v_sad_u8", "v_pk_mad_u16", "v_pk_lshrrev_b16", "v_cvt_f32_i32", "v_min3_i32", "v_add_co_u32", "v_sub_u32 sdwa sext byte", "v_mad_i32_i24"};
+    "v_dot4_i32_i8", "v_dot4c_i32_i8", "v_sub_co_u32", "v_add_u16", "v_sub_u16", "v_max_u16", "v_min_i16", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_or_b32", "v_lshl_or_b32", "v_and_or_b32", "v_bfi_b32", "v_sub_u32 clamp", "v_mad_u32_u24", "v_mul_u32_u24", "v_mad_u16", "v_alignbyte_b32", "v_add_u16_sdwa(sext byte)", "v_max_i16_sdwa(word1)", "v_add_u32 dpp wave_shr", "v_mov_b32 dpp wave_shr", "v_bcnt_u32_b32", "v_sad_u8", "v_pk_mad_u16", "v_pk_lshrrev_b16", "v_cvt_f32_i32", "v_min3_i32", "v_add_co_u32", "v_sub_u32 sdwa sext byte", "v_mad_i32_i24",
+    "v_sub_f32 clamp (e64)", "v_fmac_f32 x2.0", "v_pk_add_f32 neg clamp", "v_pk_fma_f32", "v_add_u32_sdwa + v_fmac_f32 (pair)", "v_bfe_i32 + v_add_u32 + v_fmac_f32 (triple)", "v_add_u32_sdwa + v_max_i32 (pair)", "v_sub_f32 clamp + v_fmac_f32 (pair)"};
 
 template <int OP>
 void run(int *d_out, unsigned long long *d_clk, int cus, int waves_per_simd)
@@ -127,7 +140,7 @@ void run(int *d_out, unsigned long long *d_clk, int cus, int waves_per_simd)
     unsigned long long clk[2];
     CHECK(hipMemcpy(clk, d_clk, sizeof clk, hipMemcpyDeviceToHost));
     const double ghz = (double)clk[0] / (double)clk[1] * 0.1;  // s_memrealtime ticks at 100 MHz
-    const int ninstr = (OP == 29) ? 2 : 1;
+    const int ninstr = (OP == 29 || OP == 68 || OP == 70 || OP == 71) ? 2 : OP == 69 ? 3 : 1;
     const double winstr_per_simd = (double)waves_per_simd * ITERS * CH * ninstr;  // wave-instructions per SIMD
     const double cyc = best * 1e-3 * ghz * 1e9 / winstr_per_simd;
     const double lane_ops = (double)blocks * 256 * ITERS * CH * ninstr / (best * 1e-3);
@@ -139,7 +152,7 @@ template <int OP>
 void run_all(int *d_out, unsigned long long *d_clk, int cus)
 {
     run<OP>(d_out, d_clk, cus, 8);
-    if constexpr (OP + 1 < 64) run_all<OP + 1>(d_out, d_clk, cus);
+    if constexpr (OP + 1 < 72) run_all<OP + 1>(d_out, d_clk, cus);
 }
 
 int main()
