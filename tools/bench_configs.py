@@ -66,8 +66,9 @@ for mode in modes:
     res["roofline"] = {"bound": "valu", "ops_per_cell": ops, "achieved": round(ops * plan.cells / dp_s / 1e12, 3),
                        "peak": round(bench.VALU_PEAK_LANE_OPS / 1e12, 2), "unit": "T lane-op/s (int32 VALU)",
                        "frac": round(ops * plan.cells / dp_s / bench.VALU_PEAK_LANE_OPS, 4),
-                       "note": "algorithmic lane-ops (SURVEY.md 8d) over the DP kernel's HIP-event time; the kernel executes "
-                               "about 21 issue units per affine cell, 12 of them for its four decision bits (profiles/r02_notes.md)"}
+                       "note": "algorithmic lane-ops (SURVEY.md 8d) over the DP kernel's HIP-event time; the affine kernels execute "
+                               "15 (DNA, 32-row strips) to 20 (protein, local) instructions per cell, 9 to 12 of them full-rate "
+                               "(profiles/r02_notes.md)"}
     ns = args.cpu_sample
     if ns < 0:
         ns = 6000 if args.config == 3 else 1200  # about 10 s on 16 threads
