@@ -480,7 +480,6 @@ __global__ void __launch_bounds__(256) ba_trace_affine_kernel(BaTraceParams P)
         if ((t >> 2) != k1_tag) {
             k1_tag = t >> 2;
             x_word = s1w[(size_t)k1_tag * 64];
-            asm volatile("" : "+v"(x_word));
         }
         return (x_word >> ((t & 3) * 8)) & 0xffu;
     };
@@ -489,7 +488,6 @@ __global__ void __launch_bounds__(256) ba_trace_affine_kernel(BaTraceParams P)
         if ((cc >> 2) != k2_tag) {
             k2_tag = cc >> 2;
             y_word = s2w[(size_t)k2_tag * 64];
-            asm volatile("" : "+v"(y_word));
         }
         return (y_word >> ((cc & 3) * 8)) & 0xffu;
     };
@@ -510,7 +508,6 @@ __global__ void __launch_bounds__(256) ba_trace_affine_kernel(BaTraceParams P)
         if (id != tag) {
             tag = id;
             q = dir[(size_t)id * 64];
-            asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));
         }
         sh = 31u - (uint32_t)(((jj - 1) % CPW) * R + r);
     };
