@@ -123,10 +123,7 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
             if (FKEY) {
                 // (volatile: left to itself the scheduler gathers these at the end of the column and runs out of registers)
                 float sc;
-                if (R == 16)  // (16-row strips keep the zero levels in SGPRs)
-                    asm volatile("v_subrev_f32 %0, %1, %2" : "=v"(sc) : "s"(fl), "v"(H));
-                else
-                    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(sc) : "v"(H), "v"(fl));
+                asm volatile("v_subrev_f32 %0, %1, %2" : "=v"(sc) : "s"(fl), "v"(H));  // (the zero level is wave-uniform: an SGPR)
                 asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(key) : "v"(sc), "v"(kscale), "v"((r & 1) ? klow1f : klow0f));
             } else
                 key = (int)(((uint32_t)(H - fl) << key_shift) + (uint32_t)((r & 1) ? klow1 : klow0));
@@ -321,8 +318,7 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, R == 16 ? 4 : BA_AFF_WPE) ba
                     // the row above the strip: row 0 (F = -inf, align_affine.go:63-64) or the previous strip's last row
                     const int top_hq = (s == 0) ? row0(j) - c : in.b[q].x;
                     int f = (s == 0) ? BA_NEG : in.b[q].y;
-                    int fl0 = BA_FBIAS + ge * (i0 + j);  // local: zero level of the row above the strip
-                    if (MODE == BA_LOCAL && R == 32) asm volatile("v_mov_b32 %0, %1" : "=v"(fl0) : "s"(fl0));  // a per-lane chain, not 32 scalars
+                    const int fl0 = BA_FBIAS + ge * (i0 + j);  // local: zero level of the row above the strip (wave-uniform: the rows' levels are an s_add each)
                     ba_affine_column<MODE, R, NIB, FKEY>(hq, e, acc, rkey, pw, top_hq, f, topdiag, c, ge, fl0, key_shift,
                                                    (1 << jbits) + (jmax - j), jmax - j, kappa);
                     if ((j - 1) % CPW == CPW - 1)
