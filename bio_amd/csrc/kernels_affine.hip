@@ -44,7 +44,13 @@
 #define BA_FBIAS 0x4B400000  // score x is held as BA_FBIAS + x: the f32 with this pattern is 2^23 + 2^22 + x
 #define BA_NEG (BA_FBIAS - (1 << 22))  // minus infinity of the E / F levels (align_affine.go:36-37, 45-46, 63-64): below every score the planner admits
 #ifndef BA_AFF_WPE
-#define BA_AFF_WPE 1  // wavefronts per SIMD the register allocator is asked to leave room for
+#define BA_AFF_WPE 3  // wavefronts per SIMD the register allocator is asked to leave room for (32-row strips, not local: 168 VGPRs)
+#endif
+#ifndef BA_AFF_PRIO
+#define BA_AFF_PRIO 0  // experiment: issue priority of the waves of a strip pipeline (0: none)
+#endif
+#ifndef BA_AFF_DOT4
+#define BA_AFF_DOT4 0  // experiment: byte profile lookup + add as one v_dot4c_i32_i8 with a one-hot selector
 #endif
 
 // Signed byte k of w through v_bfe_i32, kept out of the compiler's hands: it would fold the extraction into
@@ -99,8 +105,13 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
         if (MODE == BA_LOCAL) fl += ge;
         const int en = MODE == BA_LOCAL ? ba_max3(eo, hq[r], fl) : max(eo, hq[r]);
         const int fn = max(f, up);
+#if BA_AFF_DOT4
+        const int d = NIB ? diag + (int)__builtin_amdgcn_ubfe(pw[NIB ? r >> 3 : 0], 4 * (r & 7), 4) + kappa
+                          : __builtin_amdgcn_sdot4((int)pw[NIB ? 0 : r >> 2], 1 << (8 * (r & 3)), diag, false);
+#else
         const int d = NIB ? diag + (int)__builtin_amdgcn_ubfe(pw[NIB ? r >> 3 : 0], 4 * (r & 7), 4) + kappa
                           : diag + ba_sbyte_bfe(pw[NIB ? 0 : r >> 2], r & 3);
+#endif
         const int H = ba_max3(en, fn, d);
         const float b0 = ba_gt_bit(H, fn), b1 = ba_gt_bit(H, d), b2 = ba_gt_bit(en, eo), b3 = ba_gt_bit(fn, f);
         if ((r & 15) == 0) {  // 2^7 * 2 + bit
@@ -158,7 +169,8 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
 // NIB: 4-bit strip profile (scores w - min(w), top-free modes, R == 16): an alphabet of 20 column symbols
 // takes 10 KB of LDS per wavefront instead of 20, which doubles the wavefronts a CU holds.
 template <int MODE, int R, bool PIPE, bool NIB, bool FKEY = false>
-__global__ void __launch_bounds__(PIPE ? 512 : 256, R == 16 ? 4 : BA_AFF_WPE) ba_dp_affine_kernel(BaDpParams P)
+__global__ void __launch_bounds__(PIPE ? (R == 16 ? 1024 : 512) : 256)
+    __attribute__((amdgpu_waves_per_eu(R == 16 ? 4 : (MODE == BA_LOCAL ? 2 : BA_AFF_WPE)))) ba_dp_affine_kernel(BaDpParams P)
 {
     extern __shared__ __align__(16) uint32_t lds[];
     constexpr int HALVES = R / 16;
@@ -176,11 +188,26 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, R == 16 ? 4 : BA_AFF_WPE) ba
                                      : reinterpret_cast<const uint32_t *>(P.code2)[i - 64];
     const uint8_t *code1 = reinterpret_cast<const uint8_t *>(lds + wt_aligned);
     const uint8_t *code2 = code1 + 256;
-    // PIPE: progress words, one per wave: (round << 16) | column groups handed over so far
-    volatile uint32_t *prog = lds + wt_aligned + 128 + (size_t)waves * P.nb * (HALVES * 64 * (PB / 4));
-    int32_t *combine = reinterpret_cast<int32_t *>(lds + wt_aligned + 128 + (size_t)waves * P.nb * (HALVES * 64 * (PB / 4)) + 8);
-    if (PIPE && threadIdx.x < 8) prog[threadIdx.x] = 0;
+    // PIPE: progress words, one per wave: (round << 16) | column groups handed over so far.  They are read and written
+    // with relaxed workgroup-scope atomics, which stay ds_read_b32 / ds_write_b32: a volatile access through the generic
+    // pointer became a flat_load, and a flat operation returns out of order, so that every poll drained the wave's
+    // whole queue of stores (s_waitcnt vmcnt(0) lgkmcnt(0)).
+    uint32_t *prog = lds + wt_aligned + 128 + (size_t)waves * P.nb * (HALVES * 64 * (PB / 4));
+    int32_t *combine = reinterpret_cast<int32_t *>(prog + 16);
+    if (PIPE && threadIdx.x < 16) prog[threadIdx.x] = 0;
     __syncthreads();
+#if BA_AFF_PRIO == 1
+    if (PIPE && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#elif BA_AFF_PRIO == 2
+    if (PIPE) {  // the further down the chain, the higher
+        const int pr = wave * 4 / waves;
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    }
+#elif BA_AFF_PRIO == 3
+    if (PIPE && wave < 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
     const uint32_t b_idx = PIPE ? P.bundle_begin + blockIdx.x : P.bundle_begin + blockIdx.x * waves + wave;
     if (b_idx >= P.bundle_end) return;  // (PIPE: the whole block leaves together)
@@ -232,19 +259,24 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, R == 16 ? 4 : BA_AFF_WPE) ba
             if (avail >= need) return;
             // bounded: every wave leaves this loop even if something upstream went wrong
             for (int spin = 0; spin < (1 << 26); ++spin) {
-                avail = prog[pred];
+                avail = __hip_atomic_load(prog + pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (avail >= need) break;
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         };
-        auto publish = [&](int groups) {
+        // The boundary stores of the groups announced have been acknowledged before the word says so.  Vector-memory
+        // operations of a wave complete in issue order (MI355X_MICROARCH.md, s_waitcnt), so a group is announced ONE GROUP
+        // LATE behind `s_waitcnt vmcnt(4)`: the four boundary stores of the group just computed are younger than
+        // everything the announced groups stored, and nothing is drained.  The last announcement of a strip waits for all.
+        auto publish = [&](int groups, bool final) {
             if (!PIPE) return;
-            // the boundary stores have been acknowledged before the word says so (the fence alone may
-            // be lowered without a vmcnt wait at workgroup scope)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            prog[wave] = ((uint32_t)round << 16) + (uint32_t)groups;
+            if (final)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __hip_atomic_store(prog + wave, ((uint32_t)round << 16) + (uint32_t)groups, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
         };
         const int i0 = n - (strips - s) * R;
         const bool last_strip = (s == strips - 1);
@@ -334,12 +366,13 @@ __global__ void __launch_bounds__(PIPE ? 512 : 256, R == 16 ? 4 : BA_AFF_WPE) ba
                 const GroupIn cur = nxt;
                 nxt = fetch_group(min(cg + 1, cgs - 1));
                 column_group(cg, cur, std::true_type{});
-                publish(cg + 1);
+                publish(cg, false);  // (groups 0 .. cg - 1; this group's four stores are the younger ones)
+#ifdef BA_AFF_SCHEDB
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
-            if (full_groups < cgs) {
-                column_group(full_groups, nxt, std::false_type{});
-                publish(cgs);
-            }
+            if (full_groups < cgs) column_group(full_groups, nxt, std::false_type{});
+            publish(cgs, true);
             // a half-filled last word (R == 16, odd m): its column sits in the top half like any first column
             if (CPW == 2 && (m & 1))
                 dirs[(size_t)(m / 2) * 64] = make_uint4(acc[0] << 16, acc[1] << 16, acc[2] << 16, acc[3] << 16);
@@ -596,7 +629,7 @@ extern "C" size_t ba_dp_affine_lds_bytes(int nb, int nb4, int na_pad, int R, int
 {
     const int wt_aligned = (nb4 * na_pad + 3) & ~3;
     return (size_t)(wt_aligned + 128) * 4 + (size_t)waves * nb * (R / 16) * 64 * (nib ? 8 : 16) +
-           (8 + (size_t)waves * 3 * 64) * 4;
+           (16 + (size_t)waves * 3 * 64) * 4;
 }
 
 template <int MODE, int R>

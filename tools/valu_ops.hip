@@ -100,6 +100,18 @@ __global__ void __launch_bounds__(256) op_kernel(int *out, int seed, unsigned lo
             if (OP == 69) OPK2("v_bfe_i32 %1, %2, 8, 8\n\tv_add_u32 %0, %0, %1\n\tv_fmac_f32 %1, 2.0, %2");
             if (OP == 70) OPK2("v_add_u32_sdwa %0, sext(%2), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\tv_max_i32 %1, %1, %2");
             if (OP == 71) OPK2("v_sub_f32_e64 %1, %0, %2 clamp\n\tv_fmac_f32 %0, 2.0, %1");
+            // round 3
+            if (OP == 72) OPK("v_cvt_f32_ubyte1 %0, %1");
+            if (OP == 73) OPK("v_sub_f16_e64 %0, %0, %1 clamp");
+            if (OP == 74) OPK("v_fma_f16 %0, %0, %1, %2");
+            if (OP == 75) OPK("v_madmk_f16 %0, %0, 0x4000, %1");
+            if (OP == 76) OPK("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]");
+            if (OP == 77) OPK("v_fma_f16 %0, %0, %1, %2 op_sel:[0,1,0,0]");
+            if (OP == 78) OPK("v_cvt_f32_ubyte1 %0, %1\n\tv_add_f32 %0, %0, %2");
+            if (OP == 79) OPK("v_max_f16 %0, %0, %1\n\tv_sub_f16_e64 %0, %0, %2 clamp");
+            if (OP == 80) OPK("v_dot4c_i32_i8 %0, %1, %2\n");
+            if (OP == 81) OPK("v_pk_fma_f16 %0, %0, %1, %2");
+            if (OP == 82) OPK("v_add_f16 %0, %0, %1");
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -116,7 +128,8 @@ static const char *NAMES[] = {"v_add_u32", "v_max_i32", "v_max3_i32", "v_cmp_gt_
     "v_alignbit_b32", "v_fma_f32", "v_pk_max_f16", "v_subb_co_u32", "v_med3_i32", "v_pk_sub_i16", "v_perm_b32", "v_max_f16",
     "v_cmp_gt_i32+v_addc_co_u32 (pair)", "v_xor_b32", "v_min_i32",
     "v_dot4_i32_i8", "v_dot4c_i32_i8", "v_sub_co_u32", "v_add_u16", "v_sub_u16", "v_max_u16", "v_min_i16", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_or_b32", "v_lshl_or_b32", "v_and_or_b32", "v_bfi_b32", "v_sub_u32 clamp", "v_mad_u32_u24", "v_mul_u32_u24", "v_mad_u16", "v_alignbyte_b32", "v_add_u16_sdwa(sext byte)", "v_max_i16_sdwa(word1)", "v_add_u32 dpp wave_shr", "v_mov_b32 dpp wave_shr", "v_bcnt_u32_b32", "v_sad_u8", "v_pk_mad_u16", "v_pk_lshrrev_b16", "v_cvt_f32_i32", "v_min3_i32", "v_add_co_u32", "v_sub_u32 sdwa sext byte", "v_mad_i32_i24",
-    "v_sub_f32 clamp (e64)", "v_fmac_f32 x2.0", "v_pk_add_f32 neg clamp", "v_pk_fma_f32", "v_add_u32_sdwa + v_fmac_f32 (pair)", "v_bfe_i32 + v_add_u32 + v_fmac_f32 (triple)", "v_add_u32_sdwa + v_max_i32 (pair)", "v_sub_f32 clamp + v_fmac_f32 (pair)"};
+    "v_sub_f32 clamp (e64)", "v_fmac_f32 x2.0", "v_pk_add_f32 neg clamp", "v_pk_fma_f32", "v_add_u32_sdwa + v_fmac_f32 (pair)", "v_bfe_i32 + v_add_u32 + v_fmac_f32 (triple)", "v_add_u32_sdwa + v_max_i32 (pair)", "v_sub_f32 clamp + v_fmac_f32 (pair)",
+    "v_cvt_f32_ubyte1", "v_sub_f16 clamp (e64)", "v_fma_f16", "v_madmk_f16", "v_fma_mix_f32", "v_fma_f16 op_sel hi", "v_cvt_f32_ubyte1 + v_add_f32 (pair)", "v_max_f16 + v_sub_f16 clamp (pair)", "v_dot4c_i32_i8 again", "v_pk_fma_f16", "v_add_f16"};
 
 template <int OP>
 void run(int *d_out, unsigned long long *d_clk, int cus, int waves_per_simd)
@@ -140,7 +153,7 @@ void run(int *d_out, unsigned long long *d_clk, int cus, int waves_per_simd)
     unsigned long long clk[2];
     CHECK(hipMemcpy(clk, d_clk, sizeof clk, hipMemcpyDeviceToHost));
     const double ghz = (double)clk[0] / (double)clk[1] * 0.1;  // s_memrealtime ticks at 100 MHz
-    const int ninstr = (OP == 29 || OP == 68 || OP == 70 || OP == 71) ? 2 : OP == 69 ? 3 : 1;
+    const int ninstr = (OP == 29 || OP == 68 || OP == 70 || OP == 71 || OP == 78 || OP == 79) ? 2 : OP == 69 ? 3 : 1;
     const double winstr_per_simd = (double)waves_per_simd * ITERS * CH * ninstr;  // wave-instructions per SIMD
     const double cyc = best * 1e-3 * ghz * 1e9 / winstr_per_simd;
     const double lane_ops = (double)blocks * 256 * ITERS * CH * ninstr / (best * 1e-3);
@@ -152,7 +165,7 @@ template <int OP>
 void run_all(int *d_out, unsigned long long *d_clk, int cus)
 {
     run<OP>(d_out, d_clk, cus, 8);
-    if constexpr (OP + 1 < 72) run_all<OP + 1>(d_out, d_clk, cus);
+    if constexpr (OP + 1 < 83) run_all<OP + 1>(d_out, d_clk, cus);
 }
 
 int main()
@@ -163,6 +176,10 @@ int main()
     unsigned long long *d_clk;
     CHECK(hipMalloc(&d_out, (size_t)prop.multiProcessorCount * 8 * 256 * sizeof(int)));
     CHECK(hipMalloc(&d_clk, 16));
+    if (getenv("VALU_OPS_FROM")) {  // only the newer cases
+        run_all<72>(d_out, d_clk, prop.multiProcessorCount);
+        return 0;
+    }
     run_all<0>(d_out, d_clk, prop.multiProcessorCount);
     // occupancy sweep for two representative ops
     for (int w : {1, 2, 4}) { run<0>(d_out, d_clk, prop.multiProcessorCount, w); run<1>(d_out, d_clk, prop.multiProcessorCount, w); }
