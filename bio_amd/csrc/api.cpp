@@ -507,7 +507,10 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         const uint64_t sz_s1w = strips * R / 4 * 64, sz_s2w = (uint64_t)((m + 3) / 4) * 64;
         // boundary deltas: two buffers (strip parity) of ceil(m / F) words per lane, F >= 4
         // (affine: two buffers of (hq, F') per column and lane; four decision planes per column word)
-        const uint64_t sz_hb = pl->affine ? 2 * (uint64_t)m * 64 * 2 : 2 * (uint64_t)((m + 3) / 4 + 1) * 64;
+        // (affine local: behind them, the best cell of every strip, 16 bytes per lane -- the strips of a bundle are
+        // spread over the waves of a block)
+        const uint64_t sz_hb = pl->affine ? 2 * (uint64_t)m * 64 * 2 + (pl->mode == BIOALIGN_LOCAL ? strips * 64 * 4 : 0)
+                                          : 2 * (uint64_t)((m + 3) / 4 + 1) * 64;
         const uint64_t sz_dir = pl->affine ? strips * ((m + cpw - 1) / cpw) * 64 * 4
                                            : strips * (uint64_t)((m + 3) / 4) * 64 * chw;
         const uint64_t rec_cap = ((uint64_t)n + m) / 16 + 2;  // header + ceil((n + m) / 16) records
@@ -609,11 +612,13 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         const uint64_t pipe_below = env_u64("BIOALIGN_PIPE_BELOW", R == 16 ? ~0ull : 6144);
         pl->pipe = strips_max >= 2 && pl->bundles.size() < pipe_below;
         if (pl->pipe) {
+            const int waves_max = R == 16 ? 16 : (pl->mode == BIOALIGN_LOCAL ? 8 : 12);  // (1024 threads of 128 VGPRs, 768 of 168, local: 512 of 256: kernels_affine.hip)
             pl->waves = std::min(8, std::max(2, strips_max));
             // the waves of a block take strips w, w + W, ...: seven waves when that leaves fewer of them idle in the last
             // round than eight (19 strips: 7 + 7 + 5 instead of 8 + 8 + 3; config 3 1969 -> 2032 GCUPS)
             if (strips_max > 8 && (strips_max + 6) / 7 * 7 < (strips_max + 7) / 8 * 8) pl->waves = 7;
-            if (const uint64_t w = env_u64("BIOALIGN_PIPE_WAVES", 0)) pl->waves = (int)std::min<uint64_t>(std::max<uint64_t>(w, 2), 8);
+            if (const uint64_t w = env_u64("BIOALIGN_PIPE_WAVES", 0))
+                pl->waves = (int)std::min<uint64_t>(std::max<uint64_t>(w, 2), (uint64_t)waves_max);
             while (pl->waves > 2 && ba_dp_affine_lds_bytes(pl->nb, pl->nb4, pl->na_pad, R, pl->waves, pl->nib) > 80 * 1024)
                 --pl->waves;
             if ((max_m + 3) / 4 >= 65536) pl->pipe = 0;  // progress word: 16 bits of column groups
@@ -777,6 +782,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             dp.nib = pl->nib;
             dp.kappa = pl->kappa;
             dp.fkey = pl->fkey;
+            dp.pipe_bundles = (int)env_u64("BIOALIGN_PIPE_BUNDLES", 1);
             const bool timed = pl->ev_used < pl->ev0.size();
             if (timed) HIP_TRY(ctx, hipEventRecord(pl->ev0[pl->ev_used], st));
             if (pl->affine)

@@ -65,6 +65,7 @@ struct BaDpParams {
     int nib;               // affine, large alphabets: the strip profile holds 4-bit scores w - kappa0 (kernels_affine.hip)
     int kappa;             // ... and this is added back with the diagonal: min(w) + open + ext
     int fkey;              // affine local: the best-cell keys fit 24 bits and are built as floats (kernels_affine.hip)
+    int pipe_bundles;      // affine strip pipeline: bundles a block runs back to back (kernels_affine.hip)
 };
 
 struct BaTraceParams {

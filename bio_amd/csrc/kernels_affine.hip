@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -169,7 +170,7 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
 // NIB: 4-bit strip profile (scores w - min(w), top-free modes, R == 16): an alphabet of 20 column symbols
 // takes 10 KB of LDS per wavefront instead of 20, which doubles the wavefronts a CU holds.
 template <int MODE, int R, bool PIPE, bool NIB, bool FKEY = false>
-__global__ void __launch_bounds__(PIPE ? (R == 16 ? 1024 : 512) : 256)
+__global__ void __launch_bounds__(PIPE ? (R == 16 ? 1024 : (MODE == BA_LOCAL ? 512 : 768)) : 256)
     __attribute__((amdgpu_waves_per_eu(R == 16 ? 4 : (MODE == BA_LOCAL ? 2 : BA_AFF_WPE)))) ba_dp_affine_kernel(BaDpParams P)
 {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -193,7 +194,6 @@ __global__ void __launch_bounds__(PIPE ? (R == 16 ? 1024 : 512) : 256)
     // pointer became a flat_load, and a flat operation returns out of order, so that every poll drained the wave's
     // whole queue of stores (s_waitcnt vmcnt(0) lgkmcnt(0)).
     uint32_t *prog = lds + wt_aligned + 128 + (size_t)waves * P.nb * (HALVES * 64 * (PB / 4));
-    int32_t *combine = reinterpret_cast<int32_t *>(prog + 16);
     if (PIPE && threadIdx.x < 16) prog[threadIdx.x] = 0;
     __syncthreads();
 #if BA_AFF_PRIO == 1
@@ -209,15 +209,13 @@ __global__ void __launch_bounds__(PIPE ? (R == 16 ? 1024 : 512) : 256)
     if (PIPE && wave < 4) __builtin_amdgcn_s_setprio(1);
 #endif
 
-    const uint32_t b_idx = PIPE ? P.bundle_begin + blockIdx.x : P.bundle_begin + blockIdx.x * waves + wave;
+    // PIPE: the block is persistent -- it takes bundles blockIdx.x, blockIdx.x + gridDim.x, ... and its waves run the
+    // strips of that whole sequence round robin, so the pipeline never drains between bundles: strip 0 of the next
+    // bundle (which waits for nobody) starts while the last strips of the current one are still on their way.
+    uint32_t b_idx = PIPE ? P.bundle_begin + blockIdx.x : P.bundle_begin + blockIdx.x * waves + wave;
     if (b_idx >= P.bundle_end) return;  // (PIPE: the whole block leaves together)
-    const BaBundle B = P.bundles[b_idx];
-    const int n = (int)B.n, m = (int)B.m;
+    const uint32_t b_step = PIPE ? gridDim.x : 0u;
     const int ge = P.gap_ext, c = P.gap_open - P.gap_ext;
-    const int strips = (n + R - 1) / R;
-    const int cgs = (m + 3) / 4;
-    const int cws = (m + CPW - 1) / CPW;
-    const int front = strips * R - n;
     constexpr bool top_free = (MODE == BA_LOCAL || MODE == BA_FITTING);
     constexpr bool left_free = (MODE == BA_LOCAL || MODE == BA_OVERLAP);
 
@@ -225,16 +223,34 @@ __global__ void __launch_bounds__(PIPE ? (R == 16 ? 1024 : 512) : 256)
     uint8_t *prof_lane = prof + lane * PB;
     const int kappa = P.kappa;
 
-    // the row a strip hands to the next one: (hq, F') per column, two buffers by strip parity
-    int2 *bnd = reinterpret_cast<int2 *>(P.hb + B.hb_off) + lane;
-    uint4 *dir = reinterpret_cast<uint4 *>(P.dir + B.dir_off) + lane;
-    const uint32_t *s1w = P.s1w + B.s1w_off + lane;
-    const uint32_t *s2w = P.s2w + B.s2w_off + lane;
-
-    // local: position key (see ba_affine_column); jbits covers 1..m
-    const int jbits = 32 - __builtin_clz((uint32_t)(m | 1));
-    const int key_shift = jbits + 1;
-    const int jmax = (1 << jbits) - 1;
+    // the bundle in hand (wave-uniform)
+    int n, m, strips, cgs, cws, front, jbits, key_shift, jmax;
+    uint32_t b_first, b_count;
+    int2 *bnd;          // the row a strip hands to the next one: (hq, F') per column, two buffers by strip parity
+    BaLocalBest *cand;  // PIPE, local: the best cell of every strip, [strip][lane] (behind the two boundary buffers)
+    uint4 *dir;
+    const uint32_t *s1w, *s2w;
+    auto open_bundle = [&]() {
+        const BaBundle B = P.bundles[b_idx];
+        n = (int)B.n;
+        m = (int)B.m;
+        strips = (n + R - 1) / R;
+        cgs = (m + 3) / 4;
+        cws = (m + CPW - 1) / CPW;
+        front = strips * R - n;
+        b_first = B.first;
+        b_count = B.count;
+        bnd = reinterpret_cast<int2 *>(P.hb + B.hb_off) + lane;
+        cand = reinterpret_cast<BaLocalBest *>(P.hb + B.hb_off + (size_t)4 * m * 64) + lane;
+        dir = reinterpret_cast<uint4 *>(P.dir + B.dir_off) + lane;
+        s1w = P.s1w + B.s1w_off + lane;
+        s2w = P.s2w + B.s2w_off + lane;
+        // local: position key (see ba_affine_column); jbits covers 1..m
+        jbits = 32 - __builtin_clz((uint32_t)(m | 1));
+        key_shift = jbits + 1;
+        jmax = (1 << jbits) - 1;
+    };
+    open_bundle();
 
     // H'(i, 0) and H'(0, j): align_pair.go:110-113, 130-131, 158-159, 187-188 on the middle level
     // (all scores as float patterns: + BA_FBIAS)
@@ -242,15 +258,47 @@ __global__ void __launch_bounds__(PIPE ? (R == 16 ? 1024 : 512) : 256)
     auto row0 = [&](int j) { return BA_FBIAS + (top_free ? ge * j : (j >= 1 ? -c : 0)); };
 
     int best_sc = 0, best_i = 0, best_j = 0;
-    if (MODE == BA_GLOBAL) {  // strips == 0: the end cell is (0, m) on the top border
-        best_j = m;
-        best_sc = m >= 1 ? -P.gap_open - (m - 1) * ge : 0;
-    }
+    auto border_best = [&]() {  // strips == 0: the end cell lies on the top border; global: (0, m)
+        best_sc = best_i = best_j = 0;
+        if (MODE == BA_GLOBAL) {
+            best_j = m;
+            best_sc = m >= 1 ? -P.gap_open - (m - 1) * ge : 0;
+        }
+    };
+    auto write_best = [&]() {
+        if (lane < (int)b_count) {
+            BaLocalBest bb;
+            bb.score = best_sc;  // true score of the end cell
+            bb.i = best_i;
+            bb.j = best_j;
+            bb.pad = 0;
+            P.best[b_first + lane] = bb;
+        }
+    };
+    border_best();
 
     const int pred = (wave + waves - 1) % waves;  // PIPE: the wave that runs the strip above mine
     uint32_t avail = 0;                           // PIPE: last progress word seen from it
-    for (int s = PIPE ? wave : 0; s < strips; s += PIPE ? waves : 1) {
-        const int round = PIPE ? s / waves : 0;
+    int s = PIPE ? wave : 0;  // my next strip of the bundle in hand
+    for (int round = 0;; ++round, s += PIPE ? waves : 1) {
+        if (PIPE) {
+            bool out = false;
+            while (s >= strips) {  // on to the next bundle(s); every wave passes every bundle of the block
+                if (strips == 0 && wave == 0) {
+                    border_best();
+                    write_best();
+                }
+                s -= strips;
+                b_idx += b_step;
+                if (b_idx >= P.bundle_end) {
+                    out = true;
+                    break;
+                }
+                open_bundle();
+            }
+            if (out) break;
+        } else if (s >= strips)
+            break;
         // progress word of the strip above once it has handed over `groups` column groups
         const uint32_t pred_base = (uint32_t)(wave > 0 ? round : round - 1) << 16;
         auto wait_for = [&](int groups) {
@@ -295,6 +343,10 @@ __global__ void __launch_bounds__(PIPE ? (R == 16 ? 1024 : 512) : 256)
             rkey[r / 2] = 0;
         }
         int topdiag = col0(i0) - c;
+        // fitting / overlap: leftmost strict maximum of the strip's bottom row in true scores, found on the way (the
+        // last strip's is the end cell, align_pair.go:169-182; true score = H'(n, j) - ext*j up to a constant).  A scan
+        // of the stored row afterwards was a chain of 2000 dependent loads: a third of a millisecond per bundle.
+        int ev = col0(n) - c, ej = 0;
         uint4 *dirs = dir + (size_t)s * cws * 64;
         uint32_t acc[4] = {0, 0, 0, 0};
         // fitting / overlap hand the last strip's bottom row over as well: the end-cell scan reads it back
@@ -317,36 +369,56 @@ __global__ void __launch_bounds__(PIPE ? (R == 16 ? 1024 : 512) : 256)
             }
             return gi;
         };
-        auto column_group = [&](int cg, const GroupIn &in, auto full) {
+        // What a column group needs from LDS is looked up one group ahead as well: the dense codes of its four column
+        // symbols and the profile words of its first column; inside the group the next column's profile words are in
+        // flight while the current column is computed (a wave alone on its SIMD otherwise waits out every ds_read).
+        constexpr int PWN = NIB ? R / 8 : R / 4;
+        constexpr bool STAGE = PIPE && (R == 32 || NIB);  // (where the registers allow it: not one wavefront per bundle, not 16-row strips with a byte profile)
+        struct Staged {
+            uint32_t bcode[4];
+            uint32_t pw[PWN];
+        };
+        auto load_pw = [&](uint32_t bc, uint32_t (&pw)[PWN]) {
+            if (NIB) {
+                const uint2 *pp = reinterpret_cast<const uint2 *>(prof_lane + (size_t)bc * (HALVES * 64 * 8));
+#pragma unroll
+                for (int hf = 0; hf < HALVES; ++hf) {
+                    const uint2 v = pp[hf * 64];
+                    pw[NIB ? hf * 2 + 0 : 0] = v.x;
+                    pw[NIB ? hf * 2 + 1 : 0] = v.y;
+                }
+            } else {
+                const uint4 *pp = reinterpret_cast<const uint4 *>(prof_lane + (size_t)bc * (HALVES * 64 * 16));
+#pragma unroll
+                for (int hf = 0; hf < HALVES; ++hf) {
+                    const uint4 v = pp[hf * 64];
+                    pw[NIB ? 0 : hf * 4 + 0] = v.x;
+                    pw[NIB ? 0 : hf * 4 + 1] = v.y;
+                    pw[NIB ? 0 : hf * 4 + 2] = v.z;
+                    pw[NIB ? 0 : hf * 4 + 3] = v.w;
+                }
+            }
+        };
+        auto stage = [&](const GroupIn &gi) {
+            Staged st;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st.bcode[q] = code2[(gi.sw >> (q * 8)) & 0xffu];
+            load_pw(st.bcode[0], st.pw);
+            return st;
+        };
+        auto column_group = [&](int cg, const GroupIn &in, const Staged &st, auto full) {
             constexpr bool FULL = decltype(full)::value;
             const int jbase = cg * 4 + 1;
-            uint32_t bcode[4];
+            uint32_t pw[PWN];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bcode[q] = code2[(in.sw >> (q * 8)) & 0xffu];
+            for (int k = 0; k < PWN; ++k) pw[k] = st.pw[k];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (FULL || jbase + q <= m) {
                     const int j = jbase + q;
-                    uint32_t pw[NIB ? R / 8 : R / 4];
-                    if (NIB) {
-                        const uint2 *pp = reinterpret_cast<const uint2 *>(prof_lane + (size_t)bcode[q] * (HALVES * 64 * 8));
-#pragma unroll
-                        for (int hf = 0; hf < HALVES; ++hf) {
-                            const uint2 v = pp[hf * 64];
-                            pw[NIB ? hf * 2 + 0 : 0] = v.x;
-                            pw[NIB ? hf * 2 + 1 : 0] = v.y;
-                        }
-                    } else {
-                        const uint4 *pp = reinterpret_cast<const uint4 *>(prof_lane + (size_t)bcode[q] * (HALVES * 64 * 16));
-#pragma unroll
-                        for (int hf = 0; hf < HALVES; ++hf) {
-                            const uint4 v = pp[hf * 64];
-                            pw[NIB ? 0 : hf * 4 + 0] = v.x;
-                            pw[NIB ? 0 : hf * 4 + 1] = v.y;
-                            pw[NIB ? 0 : hf * 4 + 2] = v.z;
-                            pw[NIB ? 0 : hf * 4 + 3] = v.w;
-                        }
-                    }
+                    uint32_t pwn[PWN];
+                    if (!STAGE && q > 0) load_pw(st.bcode[q], pw);
+                    if (STAGE && q < 3 && (FULL || jbase + q + 1 <= m)) load_pw(st.bcode[q < 3 ? q + 1 : 3], pwn);
                     // the row above the strip: row 0 (F = -inf, align_affine.go:63-64) or the previous strip's last row
                     const int top_hq = (s == 0) ? row0(j) - c : in.b[q].x;
                     int f = (s == 0) ? BA_NEG : in.b[q].y;
@@ -356,50 +428,36 @@ __global__ void __launch_bounds__(PIPE ? (R == 16 ? 1024 : 512) : 256)
                     if ((j - 1) % CPW == CPW - 1)
                         dirs[(size_t)((j - 1) / CPW) * 64] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
                     if (write_bnd) bnd_wr[(size_t)(j - 1) * 64] = make_int2(hq[R - 1], f);
+                    if (MODE == BA_FITTING || MODE == BA_OVERLAP) {
+                        const int v = hq[R - 1] - ge * j;
+                        ej = v > ev ? j : ej;
+                        ev = max(ev, v);
+                    }
+                    if (STAGE && q < 3 && (FULL || jbase + q + 1 <= m)) {
+#pragma unroll
+                        for (int k = 0; k < PWN; ++k) pw[k] = pwn[k];
+                    }
                 }
             }
         };
         const int full_groups = m / 4;
         if (cgs > 0) {
             GroupIn nxt = fetch_group(0);
+            // (the first group's loads are waited for HERE: left pending into the loop, the compiler's counter state at the
+            // loop head asks for `vmcnt(5)` in every iteration, which also waits for all of the previous group's stores)
+            asm volatile("" : "+v"(nxt.sw), "+v"(nxt.b[0].x), "+v"(nxt.b[1].x), "+v"(nxt.b[2].x), "+v"(nxt.b[3].x));
+            asm volatile("" : "+v"(nxt.b[0].y), "+v"(nxt.b[1].y), "+v"(nxt.b[2].y), "+v"(nxt.b[3].y));
+            Staged nst;
+            if (STAGE) nst = stage(nxt);
             for (int cg = 0; cg < full_groups; ++cg) {
                 const GroupIn cur = nxt;
+                const Staged cst = STAGE ? nst : stage(cur);
                 nxt = fetch_group(min(cg + 1, cgs - 1));
-                column_group(cg, cur, std::true_type{});
+                column_group(cg, cur, cst, std::true_type{});
+                if (STAGE) nst = stage(nxt);
                 publish(cg, false);  // (groups 0 .. cg - 1; this group's four stores are the younger ones)
-#ifdef BA_AFF_SCHEDB
-                __builtin_amdgcn_sched_barrier(0);
-#endif
             }
-            if (full_groups < cgs) column_group(full_groups, nxt, std::false_type{});
-            publish(cgs, true);
-            // a half-filled last word (R == 16, odd m): its column sits in the top half like any first column
-            if (CPW == 2 && (m & 1))
-                dirs[(size_t)(m / 2) * 64] = make_uint4(acc[0] << 16, acc[1] << 16, acc[2] << 16, acc[3] << 16);
-        }
-
-        if (last_strip && MODE != BA_LOCAL) {
-            int ej = m, ecur = hq[R - 1];  // global: the last cell (align_pair.go:123-126)
-            if (MODE == BA_FITTING || MODE == BA_OVERLAP) {
-                // bottom row: leftmost strict maximum of the true scores, scan from column 0
-                // (align_pair.go:169-182); true score = H'(n, j) - ext*j up to a constant
-                ecur = col0(n) - c;
-                ej = 0;
-                int ev = ecur;
-                for (int j = 1; j <= m; ++j) {
-                    const int hv = bnd_wr[(size_t)(j - 1) * 64].x;
-                    const int v = hv - ge * j;
-                    if (v > ev) {
-                        ev = v;
-                        ej = j;
-                        ecur = hv;
-                    }
-                }
-            }
-            // true score of the end cell: H = hq + c - ext*(i+j)
-            best_sc = ecur - BA_FBIAS + c - ge * (n + ej);
-            best_i = n;
-            best_j = ej;
+            if (full_groups < cgs) column_group(full_groups, nxt, STAGE ? nst : stage(nxt), std::false_type{});
         }
         if (MODE == BA_LOCAL) {
             // first strict maximum in row-major order (align.go:216-221 on the middle level).
@@ -414,40 +472,64 @@ __global__ void __launch_bounds__(PIPE ? (R == 16 ? 1024 : 512) : 256)
                     best_j = jmax - (k & jmax);
                 }
             }
+            if (PIPE && !last_strip) {
+                BaLocalBest own;
+                own.score = best_sc;
+                own.i = best_i;
+                own.j = best_j;
+                own.pad = 0;
+                cand[(size_t)s * 64] = own;
+            }
         }
-    }
-    bool writer = true;
-    if (PIPE) {
-        if (MODE == BA_LOCAL) {
-            // every wave holds the best cell of its own strips; the best of all is the largest
-            // score, on ties the smallest row (the waves' strips are disjoint)
-            combine[(wave * 3 + 0) * 64 + lane] = best_sc;
-            combine[(wave * 3 + 1) * 64 + lane] = best_i;
-            combine[(wave * 3 + 2) * 64 + lane] = best_j;
-            __syncthreads();
-            writer = (wave == 0);
-            if (writer)
-                for (int w = 1; w < waves; ++w) {
-                    const int sc = combine[(w * 3 + 0) * 64 + lane], ii = combine[(w * 3 + 1) * 64 + lane];
-                    if (sc > best_sc || (sc == best_sc && sc > 0 && ii < best_i)) {
-                        best_sc = sc;
-                        best_i = ii;
-                        best_j = combine[(w * 3 + 2) * 64 + lane];
+        if (cgs > 0) {
+            publish(cgs, true);
+            // a half-filled last word (R == 16, odd m): its column sits in the top half like any first column
+            if (CPW == 2 && (m & 1))
+                dirs[(size_t)(m / 2) * 64] = make_uint4(acc[0] << 16, acc[1] << 16, acc[2] << 16, acc[3] << 16);
+        }
+
+        if (last_strip && MODE != BA_LOCAL) {
+            int ecur = hq[R - 1];  // global: the last cell (align_pair.go:123-126)
+            if (MODE == BA_FITTING || MODE == BA_OVERLAP) {
+                ecur = ev + ge * ej;
+            } else
+                ej = m;
+            // true score of the end cell: H = hq + c - ext*(i+j)
+            best_sc = ecur - BA_FBIAS + c - ge * (n + ej);
+            best_i = n;
+            best_j = ej;
+            if (PIPE) write_best();  // (the wave that ran the last strip knows the end cell)
+        }
+        if (MODE == BA_LOCAL && PIPE) {
+            // The strips of a bundle are spread over the waves: every strip leaves its own first best cell in `cand`
+            // (stored before the strip's last announcement, which waits for it), and the wave of the last strip --
+            // every other strip of the bundle has made its last announcement by then -- takes the first maximum over
+            // the strips in order, which is the first in row-major order (align.go:216-221 on the middle level).
+            if (last_strip) {
+                int bsc = 0, bi = 0, bj = 0;
+                auto take = [&](const BaLocalBest &x) {
+                    if (x.score > bsc) {
+                        bsc = x.score;
+                        bi = x.i;
+                        bj = x.j;
                     }
-                }
-        } else {
-            // the wave that ran the last strip knows the end cell (strips == 0: wave 0 holds the border case)
-            writer = strips > 0 ? (wave == (strips - 1) % waves) : (wave == 0);
+                };
+                if (cgs > 0)  // (no columns: no announcements to order the reads behind, and nothing to find)
+                    for (int t = 0; t < s; ++t) take(cand[(size_t)t * 64]);
+                BaLocalBest own;
+                own.score = best_sc;
+                own.i = best_i;
+                own.j = best_j;
+                take(own);
+                best_sc = bsc;
+                best_i = bi;
+                best_j = bj;
+                write_best();
+            }
+            best_sc = best_i = best_j = 0;
         }
     }
-    if (writer && lane < (int)B.count) {
-        BaLocalBest bb;
-        bb.score = best_sc;  // true score of the end cell
-        bb.i = best_i;
-        bb.j = best_j;
-        bb.pad = 0;
-        P.best[B.first + lane] = bb;
-    }
+    if (!PIPE) write_best();
 }
 
 // ----------------------------------------------------------------------------
@@ -629,7 +711,7 @@ extern "C" size_t ba_dp_affine_lds_bytes(int nb, int nb4, int na_pad, int R, int
 {
     const int wt_aligned = (nb4 * na_pad + 3) & ~3;
     return (size_t)(wt_aligned + 128) * 4 + (size_t)waves * nb * (R / 16) * 64 * (nib ? 8 : 16) +
-           (16 + (size_t)waves * 3 * 64) * 4;
+           16 * 4;
 }
 
 template <int MODE, int R>
@@ -637,7 +719,12 @@ static hipError_t launch_dp_aff(const BaDpParams &P, int waves, int pipe, hipStr
 {
     const uint32_t nbundles = P.bundle_end - P.bundle_begin;
     const size_t lds = ba_dp_affine_lds_bytes(P.nb, P.nb4, P.na_pad, R, waves, P.nib);
-    const dim3 grid(pipe ? nbundles : (nbundles + waves - 1) / waves), block(waves * 64);
+    dim3 grid(pipe ? nbundles : (nbundles + waves - 1) / waves), block(waves * 64);
+    int cus = 256;
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    }
     // more than 64 KB of dynamic LDS (large alphabets) has to be asked for, kernel by kernel
     auto allow = [&](auto kernel) {
         return lds > 64 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -648,11 +735,24 @@ static hipError_t launch_dp_aff(const BaDpParams &P, int waves, int pipe, hipStr
     auto go = [&](auto pipe_c, auto nib_c) {
         constexpr bool PIPE = decltype(pipe_c)::value, NIB = decltype(nib_c)::value;
         hipError_t ae;
+        // PIPE: persistent blocks, as many as the chip holds at once; each takes every grid.x-th bundle
+        auto resident = [&](auto kernel) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block.x, lds) != hipSuccess || per_cu < 1)
+                per_cu = 1;
+            // ... but not so few blocks that the dispatcher has nothing left to balance with: about `per_block`
+            // bundles each (the pipeline drains once per block, not once per bundle)
+            const uint64_t resident_blocks = (uint64_t)per_cu * (uint64_t)cus;
+            const uint64_t per_block = (uint64_t)std::max(1, P.pipe_bundles);
+            if (PIPE) grid.x = (unsigned)std::max<uint64_t>(std::min<uint64_t>(nbundles, resident_blocks), (nbundles + per_block - 1) / per_block);
+        };
         if (MODE == BA_LOCAL && P.fkey) {
             if ((ae = allow(&ba_dp_affine_kernel<MODE, R, PIPE, NIB, MODE == BA_LOCAL>)) != hipSuccess) return ae;
+            resident(&ba_dp_affine_kernel<MODE, R, PIPE, NIB, MODE == BA_LOCAL>);
             hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, PIPE, NIB, MODE == BA_LOCAL>), grid, block, lds, st, P);
         } else {
             if ((ae = allow(&ba_dp_affine_kernel<MODE, R, PIPE, NIB>)) != hipSuccess) return ae;
+            resident(&ba_dp_affine_kernel<MODE, R, PIPE, NIB>);
             hipLaunchKernelGGL((ba_dp_affine_kernel<MODE, R, PIPE, NIB>), grid, block, lds, st, P);
         }
         return hipGetLastError();
@@ -678,7 +778,7 @@ static hipError_t launch_dp_aff_mode(const BaDpParams &P, int R, int waves, int 
 extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, int waves, int pipe, hipStream_t st)
 {
     if (P.bundle_end == P.bundle_begin) return hipSuccess;
-    if (waves < 1 || waves > (pipe ? 8 : 4)) return hipErrorInvalidValue;
+    if (waves < 1 || waves > (pipe ? (R == 16 ? 16 : (mode == BA_LOCAL ? 8 : 12)) : 4)) return hipErrorInvalidValue;
     switch (mode) {
     case BA_GLOBAL: return launch_dp_aff_mode<BA_GLOBAL>(P, R, waves, pipe, st);
     case BA_LOCAL: return launch_dp_aff_mode<BA_LOCAL>(P, R, waves, pipe, st);
