@@ -47,12 +47,6 @@
 #ifndef BA_AFF_WPE
 #define BA_AFF_WPE 3  // wavefronts per SIMD the register allocator is asked to leave room for (32-row strips, not local: 168 VGPRs)
 #endif
-#ifndef BA_AFF_PRIO
-#define BA_AFF_PRIO 0  // experiment: issue priority of the waves of a strip pipeline (0: none)
-#endif
-#ifndef BA_AFF_DOT4
-#define BA_AFF_DOT4 0  // experiment: byte profile lookup + add as one v_dot4c_i32_i8 with a one-hot selector
-#endif
 
 // Signed byte k of w through v_bfe_i32, kept out of the compiler's hands: it would fold the extraction into
 // v_add_u32_sdwa, and among the full-rate float instructions of this cell an SDWA add stalls the pipeline far beyond
@@ -106,13 +100,8 @@ __device__ __forceinline__ void ba_affine_column(int (&hq)[R], int (&e)[R], uint
         if (MODE == BA_LOCAL) fl += ge;
         const int en = MODE == BA_LOCAL ? ba_max3(eo, hq[r], fl) : max(eo, hq[r]);
         const int fn = max(f, up);
-#if BA_AFF_DOT4
-        const int d = NIB ? diag + (int)__builtin_amdgcn_ubfe(pw[NIB ? r >> 3 : 0], 4 * (r & 7), 4) + kappa
-                          : __builtin_amdgcn_sdot4((int)pw[NIB ? 0 : r >> 2], 1 << (8 * (r & 3)), diag, false);
-#else
         const int d = NIB ? diag + (int)__builtin_amdgcn_ubfe(pw[NIB ? r >> 3 : 0], 4 * (r & 7), 4) + kappa
                           : diag + ba_sbyte_bfe(pw[NIB ? 0 : r >> 2], r & 3);
-#endif
         const int H = ba_max3(en, fn, d);
         const float b0 = ba_gt_bit(H, fn), b1 = ba_gt_bit(H, d), b2 = ba_gt_bit(en, eo), b3 = ba_gt_bit(fn, f);
         if ((r & 15) == 0) {  // 2^7 * 2 + bit
@@ -196,18 +185,6 @@ __global__ void __launch_bounds__(PIPE ? (R == 16 ? 1024 : (MODE == BA_LOCAL ? 5
     uint32_t *prog = lds + wt_aligned + 128 + (size_t)waves * P.nb * (HALVES * 64 * (PB / 4));
     if (PIPE && threadIdx.x < 16) prog[threadIdx.x] = 0;
     __syncthreads();
-#if BA_AFF_PRIO == 1
-    if (PIPE && wave >= 4) __builtin_amdgcn_s_setprio(1);
-#elif BA_AFF_PRIO == 2
-    if (PIPE) {  // the further down the chain, the higher
-        const int pr = wave * 4 / waves;
-        if (pr == 1) __builtin_amdgcn_s_setprio(1);
-        if (pr == 2) __builtin_amdgcn_s_setprio(2);
-        if (pr == 3) __builtin_amdgcn_s_setprio(3);
-    }
-#elif BA_AFF_PRIO == 3
-    if (PIPE && wave < 4) __builtin_amdgcn_s_setprio(1);
-#endif
 
     // PIPE: the block is persistent -- it takes bundles blockIdx.x, blockIdx.x + gridDim.x, ... and its waves run the
     // strips of that whole sequence round robin, so the pipeline never drains between bundles: strip 0 of the next
