@@ -9,6 +9,14 @@
 // small device helpers
 // ----------------------------------------------------------------------------
 __device__ __forceinline__ int ba_max3(int a, int b, int c) { return max(max(a, b), c); }
+// the same, kept out of the compiler's hands: left to itself it rebalances the maxima of the local cell and its running
+// maximum into 1.75 instructions per cell (v_max3 + v_max) where 1.5 v_max3 do
+__device__ __forceinline__ int ba_max3_asm(int a, int b, int c)
+{
+    int r;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // signed byte k (0..3) of a dword; hipcc folds this into the SDWA operand of the add that uses it
 __device__ __forceinline__ int ba_sbyte(uint32_t w, int k) { return (int)(int8_t)(w >> (8 * k)); }

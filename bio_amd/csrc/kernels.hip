@@ -150,9 +150,9 @@ __device__ __forceinline__ void ba_linear_column(int (&h)[R], int (&rmax)[R / 2]
         if (MODE == BA_LOCAL) {
             // max(0, max(up, left) - g, diag + w) with w + g in the profile: one max3 and one
             // saturating unsigned subtract (v_sub_u32 clamp); max3 >= up >= 0, so unsigned is exact
-            hn = (int)__builtin_elementwise_sub_sat((uint32_t)ba_max3(up, left, d), (uint32_t)g);
+            hn = (int)__builtin_elementwise_sub_sat((uint32_t)ba_max3_asm(up, left, d), (uint32_t)g);
             // running maximum per PAIR of rows: one v_max3_i32 per two cells
-            if (r & 1) rmax[r / 2] = ba_max3(rmax[r / 2], up, hn);
+            if (r & 1) rmax[r / 2] = ba_max3_asm(rmax[r / 2], up, hn);
         } else {
             hn = ba_max3(up, left, d);
         }
@@ -317,6 +317,9 @@ __global__ void __launch_bounds__(256) ba_dp_linear_kernel(BaDpParams P)
         const int full_groups = m / 4;
         auto sweep = [&](auto first_row) {
             GroupIn nxt = fetch_group(0);
+            // (the first group's loads are waited for HERE: left pending into the loop, the compiler's counter state at
+            // the loop head asks for `vmcnt(1)` in every iteration, which also waits for the previous group's stores)
+            asm volatile("" : "+v"(nxt.sw), "+v"(nxt.bw));
             for (int cg = 0; cg < full_groups; ++cg) {
                 const GroupIn cur = nxt;
                 nxt = fetch_group(min(cg + 1, cgs - 1));
