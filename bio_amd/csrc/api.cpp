@@ -176,6 +176,7 @@ struct bioalign_plan {
     int K = 2;  // residue bits per cell in the traceback matrix
     int nib = 0, kappa = 0;  // affine, large alphabets: 4-bit strip profile (kernels_affine.hip)
     int fkey = 0;            // affine local: float-built best-cell keys (kernels_affine.hip)
+    int max_n = 0, max_m = 0;  // longest s1 / s2 of the batch
     uint64_t cells = 0;
     std::vector<BaBundle> bundles;
     std::vector<Chunk> chunks;
@@ -408,6 +409,8 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
     }
     if (max_n > 0x7fffffu || max_m > 0x7fffffu)
         return ctx->fail(BIOALIGN_EUNSUPPORTED, "a pair is longer than 8M symbols; use bioalign_long");
+    pl->max_n = (int)max_n;
+    pl->max_m = (int)max_m;
 
     // int8 profile with the bias folded in (kernels.hip: biased score space)
     // (affine: every level is biased by ext*(i+j) and the strip keeps H' - (open - ext), kernels_affine.hip)
@@ -833,6 +836,8 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             tr.t_len = d_t_len;
             tr.rec = pl->d_rec;
             tr.dense_end = nullptr;
+            tr.max_n = pl->max_n;
+            tr.max_m = pl->max_m;
             if (pl->affine) {
                 HIP_TRY(ctx, ba_launch_trace_affine(tr, pl->mode, pl->R, ts));
             } else if (!pl->dense) {

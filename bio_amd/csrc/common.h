@@ -90,6 +90,7 @@ struct BaTraceParams {
     uint8_t *t1, *t2;
     uint64_t *t_off, *t_len;
     void *rec;             // move records (linear-gap walk + expansion); null only with score_only
+    int max_n, max_m;           // longest s1 / s2 of the plan (0, 0: unknown)
     const uint64_t *dense_end;  // [n_pairs] by pair: where the pair's trace ends when the traces are laid back to back
                                 // in pair order instead of into the pairs' slots (null: slots)
 };

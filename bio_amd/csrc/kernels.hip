@@ -754,6 +754,108 @@ __global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_expand_kernel(BaTracePa
     }
 }
 
+// The expansion for short pairs (the common case; the kernel above stays for bundles whose sequences do not fit the
+// LDS).  One block per bundle, eight threads per pair as above -- so that the records of a pair are read, and its
+// chunks of the traces written, as 128 contiguous bytes -- but everything whose address follows from the bundle
+// record alone is asked for at once: the bundle's packed sequences (the pack kernel's lane-interleaved words:
+// coalesced, no chase through perm -> s1_off -> bytes), the pairs' headers and each thread's first records.  The
+// sequences are staged in LDS one pair per row with an odd row stride, so that a symbol is one ds_read_u8 at
+// `row + index` and threads -- different rows, or the same row sixteen symbols apart -- hardly ever meet in a bank
+// (the per-thread staging of the kernel above conflicted on a fifth of its reads, and its blocks went through four
+// dependent round trips to memory).
+#define BA_EXPAND_PRE 3  // records per thread loaded ahead (3 * 8 * 16 trace columns: pairs of 192 + 192 in one go)
+extern "C" size_t ba_expand_bundle_lds_bytes(int max_n, int max_m, int R)
+{
+    const size_t w1 = (size_t)((max_n + R - 1) / R) * R / 4, w2 = (size_t)(max_m + 3) / 4;
+    return 64 * ((w1 | 1) + (w2 | 1)) * 4 + 16;  // (+16: a record that consumes no symbol still looks at the byte behind the run)
+}
+
+__global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_expand_bundle_kernel(BaTraceParams P)
+{
+    extern __shared__ __align__(16) uint32_t xs[];
+    const uint32_t b_idx = P.bundle_begin + blockIdx.x;
+    if (b_idx >= P.bundle_end) return;
+    const BaBundle B = P.bundles[b_idx];
+    const uint32_t q = threadIdx.x / BA_EXPAND_TPP, g16 = threadIdx.x % BA_EXPAND_TPP;
+    const int R = P.rows_per_strip;
+    const int n = (int)B.n, m = (int)B.m;
+    const int strips = (n + R - 1) / R;
+    const int front = strips * R - n;
+    const int words1 = strips * R / 4, words2 = (m + 3) / 4;
+    const int stride1 = words1 | 1, stride2 = words2 | 1;  // dwords per pair, odd
+    const bool live = q < B.count;
+    const BaMoveRec *recs = reinterpret_cast<const BaMoveRec *>(P.rec) + B.rec_off + (size_t)q * B.rec_cap + 1;
+    BaMoveRec hd;
+    hd.ops = hd.i = hd.j = hd.count = 0;
+    BaMoveRec pre[BA_EXPAND_PRE];
+    if (live) {
+        hd = recs[-1];
+#pragma unroll
+        for (int k = 0; k < BA_EXPAND_PRE; ++k)
+            pre[k] = recs[min((uint32_t)(g16 + k * BA_EXPAND_TPP), B.rec_cap - 2)];
+    }
+    {
+        const uint32_t *s1w = P.s1w + B.s1w_off, *s2w = P.s2w + B.s2w_off;
+        uint32_t *x1 = xs, *x2 = xs + 64 * stride1;
+        for (int idx = threadIdx.x; idx < words1 * 64; idx += 64 * BA_EXPAND_TPP) x1[(idx & 63) * stride1 + (idx >> 6)] = s1w[idx];
+        for (int idx = threadIdx.x; idx < words2 * 64; idx += 64 * BA_EXPAND_TPP) x2[(idx & 63) * stride2 + (idx >> 6)] = s2w[idx];
+    }
+    __syncthreads();
+    if (!live) return;
+    const uint32_t p = hd.count;
+    const uint64_t len = hd.ops;
+    const bool dense = P.dense_end != nullptr;
+    const uint64_t end = dense ? P.dense_end[p] : ((uint64_t)hd.i | ((uint64_t)hd.j << 32));
+    const uint32_t nrec = (uint32_t)((len + 15) / 16);
+    const uint32_t gs = P.gap_symbol;
+    const bool al1 = (((uint64_t)P.t1 + end) & 15u) == 0, al2 = (((uint64_t)P.t2 + end) & 15u) == 0;
+    const uint8_t *row1 = reinterpret_cast<const uint8_t *>(xs + q * stride1) + front;  // row1[x] = s1[x]
+    const uint8_t *row2 = reinterpret_cast<const uint8_t *>(xs + 64 * stride1 + q * stride2);
+    auto expand = [&](const BaMoveRec &rr, uint32_t r) {
+        const uint32_t valid = rr.count >= 16 ? 0xffffffffu : ((1u << (2 * rr.count)) - 1u);
+        const uint32_t lo = rr.ops & 0x55555555u, hi = (rr.ops >> 1) & 0x55555555u;
+        const uint32_t is_left = lo & ~hi & valid, is_up = ~lo & ~hi & 0x55555555u & valid;
+        const uint32_t c1 = rr.count - __popc(is_left), c2 = rr.count - __popc(is_up);  // symbols consumed
+        // the record consumes s1[i - c1 .. i - 1] and s2[j - c2 .. j - 1] (0-based), from the top down
+        const uint8_t *b1 = row1 + ((int)rr.i - (int)c1), *b2 = row2 + ((int)rr.j - (int)c2);
+        uint32_t a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+        // codes beyond rr.count are 0 (= up): they only ever produce bytes that are not stored
+        int u1 = (int)c1, u2 = (int)c2;  // symbols of the runs not yet used, taken from the top down
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t mv = (rr.ops >> (2 * k)) & 3u;
+            u1 -= (mv != BA_MV_LEFT);
+            u2 -= (mv != BA_MV_UP);
+            const uint32_t xq = b1[max(u1, 0)], yq = b2[max(u2, 0)];
+            const uint32_t x = mv == BA_MV_LEFT ? gs : xq;
+            const uint32_t y = mv == BA_MV_UP ? gs : yq;
+            // code k is trace column end - 16r - 1 - k: byte 15 - k of the record's 16-byte chunk
+            a[(15 - k) >> 2] |= x << (((15 - k) & 3) * 8);
+            b[(15 - k) >> 2] |= y << (((15 - k) & 3) * 8);
+        }
+        const uint64_t chunk = end - 16ull * (r + 1);
+        if (rr.count == 16 && (al1 || dense)) {
+            // (dense layout: 16-byte stores at whatever alignment the trace's end has -- global memory takes them)
+            const uint4 v = make_uint4(a[0], a[1], a[2], a[3]);
+            __builtin_memcpy(P.t1 + chunk, &v, 16);
+        } else {
+            for (uint32_t k = 0; k < rr.count; ++k) P.t1[chunk + 15 - k] = (uint8_t)(a[(15 - k) >> 2] >> (((15 - k) & 3) * 8));
+        }
+        if (rr.count == 16 && (al2 || dense)) {
+            const uint4 v = make_uint4(b[0], b[1], b[2], b[3]);
+            __builtin_memcpy(P.t2 + chunk, &v, 16);
+        } else {
+            for (uint32_t k = 0; k < rr.count; ++k) P.t2[chunk + 15 - k] = (uint8_t)(b[(15 - k) >> 2] >> (((15 - k) & 3) * 8));
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < BA_EXPAND_PRE; ++k) {
+        const uint32_t r = g16 + (uint32_t)k * BA_EXPAND_TPP;
+        if (r < nrec) expand(pre[k], r);
+    }
+    for (uint32_t r = g16 + BA_EXPAND_PRE * BA_EXPAND_TPP; r < nrec; r += BA_EXPAND_TPP) expand(recs[r], r);
+}
+
 // ----------------------------------------------------------------------------
 // host-side launchers (called from api.cpp)
 // ----------------------------------------------------------------------------
@@ -945,7 +1047,12 @@ static hipError_t launch_trace(const BaTraceParams &P, int phases, hipStream_t s
         e = hipGetLastError();
     }
     if (e != hipSuccess || P.score_only || !(phases & BA_TRACE_EXPAND)) return e;
-    hipLaunchKernelGGL(ba_expand_kernel, dim3(nbundles), dim3(64 * BA_EXPAND_TPP), 0, st, P);
+    // short pairs: the bundle's sequences staged in LDS (8 blocks per CU at 20 KB); otherwise thread by thread
+    const size_t xl = ba_expand_bundle_lds_bytes(P.max_n, P.max_m, R);
+    if (P.max_n > 0 && xl <= 40 * 1024 && P.s1w && P.s2w)
+        hipLaunchKernelGGL(ba_expand_bundle_kernel, dim3(nbundles), dim3(64 * BA_EXPAND_TPP), xl, st, P);
+    else
+        hipLaunchKernelGGL(ba_expand_kernel, dim3(nbundles), dim3(64 * BA_EXPAND_TPP), 0, st, P);
     return hipGetLastError();
 }
 
