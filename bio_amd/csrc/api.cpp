@@ -612,7 +612,10 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         // strips of small alphabets one wavefront per bundle stays ahead on large batches: 1752 vs 1404).
         // BIOALIGN_PIPE_BELOW=<bundles> moves the batch size below which it is used (0: never).
         const int strips_max = (int)((max_n + R - 1) / R);
-        const uint64_t pipe_below = env_u64("BIOALIGN_PIPE_BELOW", R == 16 ? ~0ull : 6144);
+        // (round 3: with the progress words in LDS proper and no drain per column group the pipeline is ahead at every
+        // batch size -- 400k reads of config 4: 3.7 against 2.7 TCUPS -- except for local mode with 32-row strips, whose
+        // pipeline kernel needs 200 VGPRs: 2.1 against 2.5 TCUPS on 500k DNA pairs)
+        const uint64_t pipe_below = env_u64("BIOALIGN_PIPE_BELOW", (R == 16 || pl->mode != BIOALIGN_LOCAL) ? ~0ull : 6144);
         pl->pipe = strips_max >= 2 && pl->bundles.size() < pipe_below;
         if (pl->pipe) {
             const int waves_max = R == 16 ? 16 : (pl->mode == BIOALIGN_LOCAL ? 8 : 12);  // (1024 threads of 128 VGPRs, 768 of 168, local: 512 of 256: kernels_affine.hip)
