@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -132,6 +133,9 @@ struct DevPool {
 static __device__ __align__(256) unsigned char scratch[BIOALIGN_NOALLOC_SCRATCH_BYTES];
 
 struct bioalign_ctx {
+    // handles that point back at the context (plans, stripes, parsed FASTA texts) hold a reference each, so that
+    // bioalign_destroy before their own destroy calls is not a use-after-free: the context goes with the last of them
+    std::atomic<int> refs{1};
     std::vector<int> devices;
     std::vector<unsigned char *> scratch_ptr;  // per entry of `devices`: that GPU's address of `scratch`
     std::shared_ptr<DevPool> pool;  // bioalign_batch's device memory (see DevPool)
@@ -162,6 +166,7 @@ struct Chunk {
 
 struct bioalign_plan {
     bioalign_ctx *ctx = nullptr;
+    bool ctx_ref = false;  // holds a reference on ctx (plans handed to the caller; the library's own plans live inside a call)
     int device = 0;
     uint64_t n_pairs = 0;
     int mode = 0;
@@ -314,7 +319,13 @@ extern "C" bioalign_ctx *bioalign_create(const int *device_ids, int n_devices)
     return ctx;
 }
 
-extern "C" void bioalign_destroy(bioalign_ctx *ctx) { delete ctx; }
+static void ctx_retain(bioalign_ctx *ctx) { ctx->refs.fetch_add(1, std::memory_order_relaxed); }
+static void ctx_release(bioalign_ctx *ctx)
+{
+    if (ctx && ctx->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete ctx;
+}
+
+extern "C" void bioalign_destroy(bioalign_ctx *ctx) { ctx_release(ctx); }
 
 extern "C" const char *bioalign_last_error(const bioalign_ctx *ctx)
 {
@@ -338,7 +349,9 @@ extern "C" void bioalign_plan_destroy(bioalign_plan *pl)
     for (hipEvent_t e : pl->ev_slice) (void)hipEventDestroy(e);
     if (pl->ev_side_done) (void)hipEventDestroy(pl->ev_side_done);
     if (pl->side) (void)hipStreamDestroy(pl->side);
+    bioalign_ctx *held = pl->ctx_ref ? pl->ctx : nullptr;
     delete pl;
+    ctx_release(held);
 }
 
 extern "C" uint64_t bioalign_plan_workspace_bytes(const bioalign_plan *pl) { return pl ? pl->ws_bytes : 0; }
@@ -716,6 +729,8 @@ extern "C" bioalign_plan *bioalign_plan_create(bioalign_ctx *ctx, int device_ind
     }
     bioalign_plan *pl = new bioalign_plan;
     pl->ctx = ctx;
+    pl->ctx_ref = true;
+    ctx_retain(ctx);
     pl->device = device_index;
     if (plan_build(pl, in) != 0) {
         bioalign_plan_destroy(pl);
@@ -934,6 +949,11 @@ extern "C" int bioalign_run_noalloc(bioalign_ctx *ctx, int device_index, const b
         return ctx->fail(BIOALIGN_EINVAL, "device index %d out of range", device_index);
     if (in->n_pairs == 0) return 0;
     HIP_TRY(ctx, hipSetDevice(ctx->devices[device_index]));
+    // One call at a time per GPU, whatever the context, thread or stream: every call carves its workspace out of that
+    // GPU's one `scratch` array (the array belongs to the code object, not to a context).  The call blocks until its
+    // work is done, so holding the lock for its duration costs nothing a correct caller could have had.
+    static std::mutex noalloc_mu[64];
+    std::lock_guard<std::mutex> noalloc_guard(noalloc_mu[(unsigned)ctx->devices[device_index] % 64u]);
     bioalign_plan pl;  // (host object only; nothing of it outlives the call)
     pl.ctx = ctx;
     pl.device = device_index;
@@ -1424,6 +1444,7 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
 // One column stripe of one pair on one device (also the C ABI's bioalign_stripe).
 struct bioalign_stripe {
     bioalign_ctx *ctx = nullptr;
+    bool ctx_ref = false;  // holds a reference on ctx (stripes handed to the caller)
     int dev = 0;          // index into ctx->devices
     int mode = 0, T = 8, K = 2;
     uint64_t n = 0, c0 = 0, m = 0, m_total = 0, wps = 0, strips = 0, nsuper = 0;
@@ -1943,10 +1964,18 @@ extern "C" bioalign_stripe *bioalign_stripe_create(bioalign_ctx *ctx, int device
         delete x;
         return nullptr;
     }
+    x->ctx_ref = true;
+    ctx_retain(ctx);
     return x;
 }
 
-extern "C" void bioalign_stripe_destroy(bioalign_stripe *x) { delete x; }
+extern "C" void bioalign_stripe_destroy(bioalign_stripe *x)
+{
+    if (!x) return;
+    bioalign_ctx *held = x->ctx_ref ? x->ctx : nullptr;
+    delete x;
+    ctx_release(held);
+}
 
 extern "C" uint64_t bioalign_stripe_rows(const bioalign_stripe *x) { return x ? x->n : 0; }
 
@@ -2199,6 +2228,7 @@ extern "C" bioalign_fasta *bioalign_fasta_parse(bioalign_ctx *ctx, int device_in
         delete F;
         return nullptr;
     }
+    ctx_retain(ctx);
     return F;
 }
 
@@ -2221,6 +2251,7 @@ extern "C" bioalign_fasta *bioalign_fasta_parse_reader(bioalign_ctx *ctx, int de
         delete F;
         return nullptr;
     }
+    ctx_retain(ctx);
     return F;
 }
 extern "C" int64_t bioalign_fasta_too_long_at(const bioalign_fasta *F) { return F ? F->too_long_at : -1; }
@@ -2229,7 +2260,9 @@ extern "C" void bioalign_fasta_destroy(bioalign_fasta *F)
 {
     if (!F) return;
     (void)hipSetDevice(F->ctx->devices[F->dev]);
+    bioalign_ctx *held = F->ctx;
     delete F;
+    ctx_release(held);
 }
 extern "C" uint64_t bioalign_fasta_count(const bioalign_fasta *F) { return F ? F->n_records : 0; }
 extern "C" uint64_t bioalign_fasta_bytes(const bioalign_fasta *F) { return F ? F->total : 0; }

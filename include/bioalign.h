@@ -129,8 +129,9 @@ typedef struct {
 
 /* Opens the engine on the given HIP devices (NULL / 0 = device 0 only). */
 bioalign_ctx *bioalign_create(const int *device_ids, int n_devices);
-/* Closes the engine.  Plans, fasta objects and stripes made from a context hold a pointer to it: destroy them
- * BEFORE the context (destroying one afterwards reads freed memory). */
+/* Closes the engine.  Plans, fasta objects and stripes made from a context hold a reference on it: the context's
+ * memory goes with the last of them, so the order of the destroy calls does not matter (no other call may use the
+ * context handle after bioalign_destroy). */
 void bioalign_destroy(bioalign_ctx *ctx);
 /* Message of the last failure on this context (or of a failed create when ctx is NULL). */
 const char *bioalign_last_error(const bioalign_ctx *ctx);
@@ -331,7 +332,8 @@ int bioalign_all_ordered_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, in
 
 /*
  * One entry point that allocates nothing.  It has no counterpart in the reference; it is for callers that cannot
- * call hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  It is
+ * call hipMalloc: tight serving loops, harnesses that forbid allocation.  (Not for a stream under graph capture: the
+ * call uploads its tables from pageable host memory and synchronises `stream` before it returns.)  It is
  * bioalign_plan_create + bioalign_plan_run + bioalign_plan_destroy in one call -- same arguments (`in` as for
  * bioalign_plan_create: host offsets give the lengths, in->s1 / s2 may be NULL; the d_ pointers as for
  * bioalign_plan_run: device memory on device `device_index` of the context), same planner, same kernels, same
@@ -343,8 +345,10 @@ int bioalign_all_ordered_pairs(bioalign_ctx *ctx, const bioalign_batch_t *in, in
  * with linear gaps, 2 bits per cell; half that many cells with affine gaps) answers BIOALIGN_EUNSUPPORTED and
  * nothing is run; BIOALIGN_DENSE_TRACES / BIOALIGN_TRACE_OPS / BIOALIGN_SCORE_ONLY / BIOALIGN_END_CELLS work as in
  * plans.  Every call on a GPU shares that GPU's array, which keeps the last call's contents (the kernels write
- * every word before they read it, nothing has to start at zero): two calls that overlap on one GPU -- from two
- * threads, contexts or streams -- race; calls on different GPUs do not.
+ * every word before they read it, nothing has to start at zero).  Calls that would overlap on one GPU -- from two
+ * threads, contexts or streams of this process -- are serialised by a per-GPU lock inside the call (it blocks until
+ * its work is done anyway); calls on different GPUs run side by side.  Two PROCESSES each hold their own copy of
+ * the array.
  */
 #define BIOALIGN_NOALLOC_SCRATCH_BYTES (64u << 20)
 int bioalign_run_noalloc(bioalign_ctx *ctx, int device_index, const bioalign_batch_t *in, const uint8_t *d_s1,

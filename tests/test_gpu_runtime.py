@@ -73,6 +73,52 @@ def test_affine_unpipelined_matches_pipelined(monkeypatch):
     assert _traces(_batch("fitting", s1, o1, s2, o2, go=5, ge=1)) == piped
 
 
+@pytest.mark.parametrize("waves,bundles", [("8", "1"), ("7", "1"), ("12", "1"), ("3", "4"), ("5", "2"), ("16", "3")])
+@pytest.mark.parametrize("mode,go", [("fitting", 5), ("local", 11), ("global", 4), ("overlap", 5)])
+def test_affine_pipeline_shapes(monkeypatch, waves, bundles, mode, go):
+    # launch shapes of the strip pipeline that the planner does not pick by itself (kernels_affine.hip): more waves than a
+    # bundle has strips (waves that own no strip of the first bundle), odd wave counts, and blocks that run several
+    # bundles back to back (BIOALIGN_PIPE_BUNDLES: strip 0 of the next bundle starts under the last strips of this one,
+    # local mode collects the strips' best cells through memory); ragged shapes, several bundles of each shape
+    rng = np.random.default_rng(int(waves) * 31 + int(bundles))
+    shapes = [(40, 90), (33, 70), (70, 33), (1, 50), (17, 0), (0, 9), (64, 64), (100, 120)]
+    l1 = np.concatenate([np.full(130, a) for a, _ in shapes])
+    l2 = np.concatenate([np.full(130, b) for _, b in shapes])
+    o1 = np.concatenate([[0], np.cumsum(l1)]).astype(np.uint64)
+    o2 = np.concatenate([[0], np.cumsum(l2)]).astype(np.uint64)
+    s1 = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(o1[-1]))]
+    s2 = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(o2[-1]))]
+    monkeypatch.setenv("BIOALIGN_PIPE_BELOW", "0")
+    ref = _traces(_batch(mode, s1, o1, s2, o2, go=go, ge=1))  # one wavefront per bundle
+    monkeypatch.delenv("BIOALIGN_PIPE_BELOW")
+    monkeypatch.setenv("BIOALIGN_PIPE_WAVES", waves)
+    monkeypatch.setenv("BIOALIGN_PIPE_BUNDLES", bundles)
+    for rows in ("16", "32"):
+        monkeypatch.setenv("BIOALIGN_STRIP_ROWS", rows)
+        assert _traces(_batch(mode, s1, o1, s2, o2, go=go, ge=1)) == ref, rows
+    oa = O.MatchAligner(1, -1)
+    for p in range(0, len(l1), 97):
+        x, y = s1[int(o1[p]):int(o1[p + 1])].tobytes(), s2[int(o2[p]):int(o2[p + 1])].tobytes()
+        want = O.AlignAffine(mode, x, y, oa, go, 1)
+        assert (ref[p][0], ref[p][1] or None, ref[p][2] or None) == want, p
+
+
+def test_context_may_be_destroyed_before_its_plans():
+    # plans, stripes and parsed FASTA texts hold a reference on their context (include/bioalign.h): any destroy order
+    s1, o1, s2, o2 = synth.dna_pairs(64, 30, 30, config=1)
+    table, c1, c2 = synth.dna_table(1, -1)
+    L = _native.lib()
+    eng = _native.Engine([0])
+    plan = eng.plan(_native.PackedBatch(s1, o1, s2, o2, "global", table, c1, c2, 1, 1))
+    fa = _native.Fasta(eng, b">a\nACGT\n>b\nGG\n")
+    h, eng._h = eng._h, None  # (the Python wrapper would close its children first: go through the C ABI)
+    L.bioalign_destroy(h)
+    assert int(L.bioalign_fasta_count(fa._h)) == 2
+    assert fa.seq_bytes().tobytes() == b"ACGTGG"  # (a call that reaches into the context: devices, error string)
+    fa.close()
+    plan.close()
+
+
 def test_limits_are_refused_not_computed_elsewhere():
     a = bio_amd.MatchAligner(1, -1)
 

@@ -98,3 +98,39 @@ def test_noalloc_refuses_what_does_not_fit():
     # and the engine still works afterwards
     small = synth.dna_pairs(64, 50, 50, config=2)
     _both_ways(eng, small, "global", table, c1, c2, 1, 1, "after a refusal")
+
+
+def test_noalloc_calls_from_two_threads_do_not_corrupt_each_other():
+    # both calls carve their workspace out of the GPU's one scratch array: a per-GPU lock inside the call serialises them
+    import threading
+    table, c1, c2 = synth.dna_table(1, -1)
+    eng = _native.Engine([0])
+    jobs = []
+    for k, (n, l) in enumerate([(3000, 120), (2500, 150)]):
+        s1, o1, s2, o2 = synth.dna_pairs(n, l, l, config=2 + k)
+        pb = _native.PackedBatch(s1, o1, s2, o2, "global" if k == 0 else "local", table, c1, c2, 1, 1)
+        d = _device_batch(s1, o1, s2, o2)
+        ref, got = _outputs(n, pb.trace_capacity, 0x55), _outputs(n, pb.trace_capacity, 0x2a)
+        plan = eng.plan(pb)
+        plan.run(*_ptrs(d, ref), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        plan.close()
+        jobs.append((pb, d, ref, got, n, torch.cuda.Stream()))
+    errs = []
+
+    def work(job):
+        pb, d, ref, got, n, st = job
+        try:
+            for _ in range(4):
+                eng.run_noalloc(pb, *_ptrs(d, got), st.cuda_stream)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for k, (pb, d, ref, got, n, st) in enumerate(jobs):
+        _same(ref, got, n, f"thread {k}")
