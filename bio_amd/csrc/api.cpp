@@ -1260,7 +1260,10 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     if (budget == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-        budget = (uint64_t)(0.7 * (double)free_b);
+        // 70 % of what is free once the pair's other buffers are taken: the checkpoint rows (8 bytes per column and
+        // workgroup), the sequences, the two traces and their move codes, the local-mode maxima
+        const uint64_t other = nsuper * ((m + 15) / 16 * 16) * 8 + (n + m) * 4 + strips * 64 * 4 * (affine ? 2 * (uint64_t)T : 1) + (1u << 20);
+        budget = (uint64_t)(0.7 * (double)(free_b > other ? free_b - other : 0));
     }
     const bool checkpointed = traces && resid_all > budget;
     if (checkpointed && (affine || in->mode == BIOALIGN_LOCAL))
@@ -1269,8 +1272,9 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     const uint64_t W_ = (uint64_t)ba_long_strips_per_group();
     // workgroups per recomputed block: as many as the budget holds (at least one)
     const uint64_t wgs_per_block = checkpointed ? std::max<uint64_t>(1, budget / (W_ * wps * 256)) : nsuper;
-    // (score only, linear gaps, not local: nothing reads residues, none are stored)
-    const bool no_resid = !traces && !affine && in->mode != BIOALIGN_LOCAL;
+    // (score only: nothing reads residues or decision words, none are stored -- local mode takes its maximum from the
+    // lanes' running maxima, the other modes read the bottom row)
+    const bool no_resid = !traces;
     const uint64_t resid_bytes = no_resid ? 0 : checkpointed ? std::min(nsuper, wgs_per_block) * W_ * wps * 256 : resid_all;
     // local: per lane its largest score (affine: per row its largest true score and the step it was reached at)
     if (in->mode == BIOALIGN_LOCAL && (rc = d_lmax.alloc(ctx, strips * 64 * 4 * (affine ? 2 * (size_t)T : 1)))) return rc;

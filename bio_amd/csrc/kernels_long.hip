@@ -724,7 +724,7 @@ __global__ void __launch_bounds__(1024) ba_long_local_find_kernel(BaLongParams P
         }
     const int M = best;
     int fi = 0, fj = 0;
-    if (M > 0) {
+    if (M > 0 && !P.no_resid) {  // (score only: no residues were stored, and nobody asks where the maximum lies)
         const int s = (int)(bk >> 6), l = (int)(bk & 63u);
         const int i0 = n - (strips - s) * RS;
         const int chunk = (m + 1023) / 1024;
@@ -790,7 +790,7 @@ __global__ void __launch_bounds__(1024) ba_long_local_find_kernel(BaLongParams P
         P.walk[3] = (uint32_t)M;
         P.walk[4] = (uint32_t)fi;
         P.walk[5] = (uint32_t)fj;
-        if (M > 0 && fi == 0) atomicAdd(P.status, 1u);  // (cannot happen: some row of the group holds M)
+        if (M > 0 && fi == 0 && !P.no_resid) atomicAdd(P.status, 1u);  // (cannot happen: some row of the group holds M)
     }
 }
 
@@ -1872,7 +1872,14 @@ static hipError_t launch_long_affine(const BaLongParams &P, int phases, hipStrea
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
     if (e != hipSuccess) return e;
     if (phases & BA_LONG_PHASE_DP) {
-        hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, 4, false, true>), dim3(P.nsuper), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+        if (P.no_resid) {  // score only: the decision words are not stored
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, 4, false, true, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds)) != hipSuccess)
+                return e;
+            hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, 4, false, true, true>), dim3(P.nsuper), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+        } else {
+            hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, 4, false, true>), dim3(P.nsuper), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (phases & BA_LONG_PHASE_WALK) {

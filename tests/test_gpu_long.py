@@ -299,6 +299,26 @@ def test_long_linear_space_traceback(budget, monkeypatch):
     assert e.value.code == bio_amd._native.ENOMEM
 
 
+def test_long_score_only_stores_no_residues(monkeypatch):
+    # score-only pairs store no residue / decision words in ANY mode, linear or affine (local mode takes its maximum from
+    # the lanes' running maxima): with a one-byte budget for the traceback matrix they still run, and give the oracle's score
+    from bio_amd import _native
+    monkeypatch.setenv("BIOALIGN_LONG_RESIDUE_BYTES", "1")
+    table, c1, c2 = synth.dna_table(1, -1)
+    eng = bio_amd.align.engine()
+    oa = O.MatchAligner(1, -1)
+    for k, (n, m) in enumerate([(700, 900), (2300, 1500), (300, 3000)]):
+        x, y = _pair(n, m, 1700 + k)
+        s1, s2 = np.frombuffer(x, np.uint8), np.frombuffer(y, np.uint8)
+        o1, o2 = np.array([0, n], np.uint64), np.array([0, m], np.uint64)
+        for mode in MODES4:
+            for go, ge in ((1, 1), (5, 1)):
+                pb = _native.PackedBatch(s1, o1, s2, o2, mode, table, c1, c2, go, ge, flags=_native.SCORE_ONLY)
+                sc = eng.long(pb)[0]
+                want = O.AlignAffine(mode, x, y, oa, go, ge)[0] if go != ge else O.AlignPair(mode, x, y, oa, go)[0]
+                assert int(sc[0]) == want, (mode, go, ge, n, m)
+
+
 def test_long_linear_space_traceback_20k(monkeypatch):
     from bio_amd import _native
     s1, o1, s2, o2 = synth.dna_pairs(1, 20_000, 20_000, config=5, sub=0.06, ins=0.02, dele=0.02)
