@@ -374,6 +374,9 @@ def run_rank(args):
                     "frac": round((traffic or dom["dir_bytes_per_pass"]) / (dom["pass_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kern,
             "dp_kernel_share_of_step": round(sum(ms for ms, _ in dp) / (elapsed * 1e3), 3),
+            # the whole step against the same roofline: the algorithmic lane-ops of every pass over the step's wall time
+            # (packing, walks and expansion included), next to `frac`, which is the dominant DP kernel alone
+            "frac_end_to_end": round(sum(op * cells_per_pass for op in ops) / VALU_PEAK_LANE_OPS / (elapsed / args.steps), 4),
         }
         ns = args.cpu_sample
         if ns < 0:  # about 10-20 s of oracle work on 16 threads
