@@ -37,6 +37,8 @@ extern "C" hipError_t ba_launch_ops_sizes(const uint64_t *t_len, uint64_t n, uin
 extern "C" hipError_t ba_launch_ops_emit(const BaTraceParams &P, hipStream_t st);
 extern "C" size_t ba_dp_affine_lds_bytes(int nb, int nb4, int na_pad, int R, int waves, int nib);
 extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, int waves, int pipe, hipStream_t st);
+extern "C" hipError_t ba_launch_dp_wide(const BaDpParams &P, int mode, int affine, hipStream_t st);
+extern "C" hipError_t ba_launch_trace_wide(const BaTraceParams &P, int mode, int affine, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_affine(const BaTraceParams &P, int mode, int R, hipStream_t st);
 
 namespace {
@@ -182,6 +184,7 @@ struct bioalign_plan {
     int nib = 0, kappa = 0;  // affine, large alphabets: 4-bit strip profile (kernels_affine.hip)
     int fkey = 0;            // affine local: float-built best-cell keys (kernels_affine.hip)
     int max_n = 0, max_m = 0;  // longest s1 / s2 of the batch
+    bool wide = false;  // scores or penalties the packed encodings of the fast kernels cannot hold: 32-bit kernels (kernels_wide.hip)
     uint64_t cells = 0;
     std::vector<BaBundle> bundles;
     std::vector<Chunk> chunks;
@@ -428,22 +431,27 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
     // int8 profile with the bias folded in (kernels.hip: biased score space)
     // (affine: every level is biased by ext*(i+j) and the strip keeps H' - (open - ext), kernels_affine.hip)
     int bias = pl->affine ? pl->gap_open + pl->gap_ext : (pl->mode == BIOALIGN_LOCAL) ? pl->gap : 2 * pl->gap;
+    // What the fast kernels' encodings cannot hold -- profile bytes outside int8, a score span beyond 8 residue bits,
+    // affine working scores beyond the float patterns' 2^22 -- runs on the WIDE kernels (kernels_wide.hip): 32-bit
+    // scores, the caller's table, a decision byte per cell.  Slow, and the reference's result for every input whose
+    // scores stay within 30 bits (align.go:76 takes any int).  BIOALIGN_WIDE=1 forces it (tests).
+    bool wide = env_u64("BIOALIGN_WIDE", 0) != 0;
     int wmax = 0, wmin = 0;
+    int64_t wabs = 0;
     for (int i = 0; i < pl->na * pl->nb; ++i) {
         const int64_t v = (int64_t)in->score_table[i] + bias;
-        if (v < -127 || v > 127)
-            return ctx->fail(BIOALIGN_EUNSUPPORTED,
-                             "score %d with gap %d does not fit the int8 profile of the fast kernels",
-                             in->score_table[i], pl->gap);
+        if (v < -127 || v > 127) wide = true;
         wmax = std::max(wmax, in->score_table[i]);
         wmin = std::min(wmin, in->score_table[i]);
+        wabs = std::max<int64_t>(wabs, std::llabs((long long)in->score_table[i]));
     }
+
     // Affine gaps over a large alphabet (proteins): the strip profile of 16 rows x nb symbols is what limits the
     // wavefronts per CU.  Where the scores span at most 16 values the profile keeps w - min(w) in 4 bits and the
     // kernel adds kappa = min(w) + open + ext back with the diagonal.  The rows of the first strip that lie above
     // the matrix must score `open` (free top row; kernels_affine.hip): nibble open - kappa = -min(w) - ext.
     int nib_pad = 0;
-    if (pl->affine && (pl->mode == BIOALIGN_LOCAL || pl->mode == BIOALIGN_FITTING) && pl->nb > 6 &&
+    if (!wide && pl->affine && (pl->mode == BIOALIGN_LOCAL || pl->mode == BIOALIGN_FITTING) && pl->nb > 6 &&
         wmax - wmin <= 15 && -wmin - pl->gap_ext >= 0 && -wmin - pl->gap_ext <= 15 &&
         env_u64("BIOALIGN_NIBBLE_PROFILE", 1) != 0) {
         pl->nib = 1;
@@ -457,33 +465,44 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
     if (!pl->affine) {
         const int64_t span = std::max<int64_t>((int64_t)wmax + 2 * (int64_t)pl->gap, 0) + 1;
         pl->K = span <= 4 ? 2 : span <= 16 ? 4 : span <= 256 ? 8 : 0;
-        if (!pl->K)
-            return ctx->fail(BIOALIGN_EUNSUPPORTED, "score span %lld does not fit 8 residue bits", (long long)span);
+        if (!pl->K) {
+            wide = true;  // (more than 8 residue bits)
+            pl->K = 8;
+        }
     }
-    if ((max_n + max_m + 2) * 128 >= (1ull << 31))
-        return ctx->fail(BIOALIGN_EUNSUPPORTED, "pair too long for 32-bit scores on the batch path");
+    if (!wide && (max_n + max_m + 2) * 128 >= (1ull << 31)) wide = true;
     if (pl->affine) {
         // working-space magnitudes stay far below the kernels' "minus infinity" and floor offsets
-        if ((max_n + max_m + 2) * (uint64_t)(128 + pl->gap_open + pl->gap_ext) >= (1ull << 22))
-            return ctx->fail(BIOALIGN_EUNSUPPORTED, "pair too long for the affine batch kernels");
+        if ((max_n + max_m + 2) * (uint64_t)(128 + pl->gap_open + pl->gap_ext) >= (1ull << 22)) wide = true;
         // local: (true score << key_shift) must fit 31 bits (position key, kernels_affine.hip)
         const int key_shift = bit_length(max_m | 1) + 1;
-        if (pl->mode == BIOALIGN_LOCAL && (min_nm_max + 1) * (uint64_t)std::max(wmax, 1) >= (1ull << (31 - key_shift)))
-            return ctx->fail(BIOALIGN_EUNSUPPORTED, "local affine scores do not fit the position key");
+        if (pl->mode == BIOALIGN_LOCAL && (min_nm_max + 1) * (uint64_t)std::max(wmax, 1) >= (1ull << (31 - key_shift))) wide = true;
         pl->fkey = pl->mode == BIOALIGN_LOCAL && (min_nm_max + 2) * (uint64_t)std::max(wmax, 1) < (1ull << (24 - std::min(key_shift, 24)));
-        if (pl->gap_open > 127)
-            return ctx->fail(BIOALIGN_EUNSUPPORTED, "gap_open %d does not fit the int8 profile", pl->gap_open);
+        if (pl->gap_open > 127) wide = true;
         pl->K = 0;
+    }
+    if (wide) {
+        // every score of the matrix (and every E / F value a finite step below one) stays within 30 bits
+        if ((double)(max_n + max_m + 2) * (double)(wabs + pl->gap_open + pl->gap_ext + 1) >= (double)(1ull << 29))
+            return ctx->fail(BIOALIGN_EUNSUPPORTED, "scores of up to %lld over %llu + %llu symbols do not fit the 32-bit scores of the GPU kernels",
+                             (long long)wabs, (unsigned long long)max_n, (unsigned long long)max_m);
+        if (pl->ops)
+            return ctx->fail(BIOALIGN_EUNSUPPORTED, "BIOALIGN_TRACE_OPS: not with scores that need the wide kernels");
+        pl->wide = true;
+        pl->nib = 0;
+        pl->fkey = 0;
+        if (!pl->affine) pl->K = 8;
     }
     // strip height and block shape: the strip profile (nb * R bytes per lane) lives in LDS
     pl->R = (pl->nb <= 6 && pl->K <= 4) ? 32 : 16;
+    if (pl->wide) pl->R = 32;  // (only the packing's row padding depends on it)
     if (const uint64_t rows = env_u64("BIOALIGN_STRIP_ROWS", 0)) {  // experiments: 16 where 32 would be chosen
         if (rows == 16) pl->R = 16;
     }
     pl->waves = 4;
-    while (pl->waves > 1 && ba_dp_linear_lds_bytes(pl->nb, pl->nb4, pl->na_pad, pl->R, pl->waves) > 40 * 1024)
+    while (!pl->wide && pl->waves > 1 && ba_dp_linear_lds_bytes(pl->nb, pl->nb4, pl->na_pad, pl->R, pl->waves) > 40 * 1024)
         pl->waves >>= 1;
-    if (ba_dp_linear_lds_bytes(pl->nb, pl->nb4, pl->na_pad, pl->R, pl->waves) > 160 * 1024)
+    if (!pl->wide && ba_dp_linear_lds_bytes(pl->nb, pl->nb4, pl->na_pad, pl->R, pl->waves) > 160 * 1024)
         return ctx->fail(BIOALIGN_EUNSUPPORTED, "alphabet of %d column symbols needs more LDS than a CU has", pl->nb);
     const int R = pl->R;
     const int chw = 4 * (R * pl->K / 32);  // residue dwords per lane per group of 4 columns
@@ -510,7 +529,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
     uint64_t o_s1w = 0, o_s2w = 0, o_hb = 0, o_dir = 0, o_rec = 0;
     uint64_t m_s1w = 0, m_s2w = 0, m_hb = 0, m_dir = 0, m_rec = 0;
     // linear gaps: the walk records its moves and a second kernel expands them (kernels.hip)
-    const bool use_rec = !pl->affine && !pl->score_only;
+    const bool use_rec = !pl->affine && !pl->score_only && !pl->wide;  // (the wide traceback writes the strings itself)
     uint32_t chunk_begin = 0;
     for (uint64_t q = 0; q < N;) {
         const uint32_t n = len1[at(q)], m = len2[at(q)];
@@ -525,10 +544,13 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         // (affine: two buffers of (hq, F') per column and lane; four decision planes per column word)
         // (affine local: behind them, the best cell of every strip, 16 bytes per lane -- the strips of a bundle are
         // spread over the waves of a block)
-        const uint64_t sz_hb = pl->affine ? 2 * (uint64_t)m * 64 * 2 + (pl->mode == BIOALIGN_LOCAL ? strips * 64 * 4 : 0)
-                                          : 2 * (uint64_t)((m + 3) / 4 + 1) * 64;
-        const uint64_t sz_dir = pl->affine ? strips * ((m + cpw - 1) / cpw) * 64 * 4
-                                           : strips * (uint64_t)((m + 3) / 4) * 64 * chw;
+        const uint64_t sz_hb = pl->wide     ? ((uint64_t)m + 1) * 64 * (pl->affine ? 2 : 1)
+                               : pl->affine ? 2 * (uint64_t)m * 64 * 2 + (pl->mode == BIOALIGN_LOCAL ? strips * 64 * 4 : 0)
+                                            : 2 * (uint64_t)((m + 3) / 4 + 1) * 64;
+        const uint64_t sz_dir_fast = pl->affine ? strips * ((m + cpw - 1) / cpw) * 64 * 4
+                                                : strips * (uint64_t)((m + 3) / 4) * 64 * chw;
+        // (wide: a decision byte per cell and lane; the H row -- and the F row -- of m + 1 scores per lane)
+        const uint64_t sz_dir = pl->wide ? (uint64_t)n * m * 16 + 64 : sz_dir_fast;
         const uint64_t rec_cap = ((uint64_t)n + m) / 16 + 2;  // header + ceil((n + m) / 16) records
         const uint64_t sz_rec = use_rec ? rec_cap * 64 : 0;  // records of 16 bytes
         const uint64_t after = (o_s1w + sz_s1w + o_s2w + sz_s2w + o_hb + sz_hb + o_dir + sz_dir) * 4 + (o_rec + sz_rec) * 16;
@@ -617,7 +639,7 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         if ((rc = dev_alloc(pl, (void **)&pl->d_len_part, ((N + 2047) / 2048 + 2) * 8))) return rc;
     }
     if ((rc = dev_alloc(pl, (void **)&pl->d_best, (N ? N : 1) * sizeof(BaLocalBest)))) return rc;
-    if (pl->affine) {
+    if (pl->affine && !pl->wide) {
         // Run the strips of a bundle as a pipeline over the waves of a block (as many waves as strips, up to
         // 8).  Few bundles: one wavefront each cannot fill 1024 SIMDs.  Many bundles: the row a strip hands
         // to the next one is read back while it is still in the L2 instead of from HBM, and the smaller work
@@ -806,7 +828,11 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             dp.pipe_bundles = (int)env_u64("BIOALIGN_PIPE_BUNDLES", 1);
             const bool timed = pl->ev_used < pl->ev0.size();
             if (timed) HIP_TRY(ctx, hipEventRecord(pl->ev0[pl->ev_used], st));
-            if (pl->affine)
+            dp.table = pl->d_table;
+            dp.wide_rows = pl->R;
+            if (pl->wide)
+                HIP_TRY(ctx, ba_launch_dp_wide(dp, pl->mode, pl->affine ? 1 : 0, st));
+            else if (pl->affine)
                 HIP_TRY(ctx, ba_launch_dp_affine(dp, pl->mode, pl->R, pl->waves, pl->pipe, st));
             else
                 HIP_TRY(ctx, ba_launch_dp_linear(dp, pl->mode, pl->R, pl->K, pl->waves, st));
@@ -856,7 +882,9 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             tr.dense_end = nullptr;
             tr.max_n = pl->max_n;
             tr.max_m = pl->max_m;
-            if (pl->affine) {
+            if (pl->wide) {
+                HIP_TRY(ctx, ba_launch_trace_wide(tr, pl->mode, pl->affine ? 1 : 0, ts));
+            } else if (pl->affine) {
                 HIP_TRY(ctx, ba_launch_trace_affine(tr, pl->mode, pl->R, ts));
             } else if (!pl->dense) {
                 HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 3, ts));

@@ -65,6 +65,8 @@ struct BaDpParams {
     int nib;               // affine, large alphabets: the strip profile holds 4-bit scores w - kappa0 (kernels_affine.hip)
     int kappa;             // ... and this is added back with the diagonal: min(w) + open + ext
     int fkey;              // affine local: the best-cell keys fit 24 bits and are built as floats (kernels_affine.hip)
+    const int32_t *table;  // wide kernels: na * nb scores as the caller gave them (kernels_wide.hip)
+    int wide_rows;         // wide kernels: rows per strip of the packed s1 words (their front padding)
     int pipe_bundles;      // affine strip pipeline: bundles a block runs back to back (kernels_affine.hip)
 };
 

@@ -119,19 +119,72 @@ def test_context_may_be_destroyed_before_its_plans():
     plan.close()
 
 
+class _Big:
+    """scores far outside the int8 profile of the fast kernels"""
+
+    def __init__(self, match, mismatch):
+        self.match, self.mismatch = match, mismatch
+
+    def Score(self, x, y):
+        return self.match if x == y else self.mismatch
+
+
 def test_limits_are_refused_not_computed_elsewhere():
+    # what the engine does NOT compute says so: negative penalties, open < extend (the reference's recurrences take them;
+    # the kernels' border and tie arguments do not), scores beyond 32 bits
     a = bio_amd.MatchAligner(1, -1)
-
-    class Big:
-        def Score(self, x, y):
-            return 300 if x == y else -300
-
-    for fn in (lambda: bio_amd.AlignPairBatch("global", [b"ACGT"], [b"ACG"], Big(), 1),
-               lambda: bio_amd.AlignPairBatch("global", [b"ACGT"], [b"ACG"], a, -1),
-               lambda: bio_amd.AlignPairBatch("global", [b"ACGT"], [b"ACG"], a, 200)):
+    for fn in (lambda: bio_amd.AlignPairBatch("global", [b"ACGT"], [b"ACG"], a, -1),
+               lambda: bio_amd.AlignAffineBatch("global", [b"ACGT"], [b"ACG"], a, 1, 3),
+               lambda: bio_amd.AlignPairBatch("global", [b"ACGT" * 50], [b"ACG" * 50], _Big(2_000_000, -2_000_000), 1)):
         with pytest.raises(_native.BioAlignError) as e:
             fn()
         assert e.value.code == _native.EUNSUPPORTED
+
+
+def _wide_pairs(seed, n_pairs=90, lo=0, hi=60):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_pairs):
+        n, m = int(rng.integers(lo, hi)), int(rng.integers(lo, hi))
+        x = bytes(b"ACGT"[k] for k in rng.integers(0, 4, n))
+        y = bytearray(x[:m].ljust(m, b"A")) if rng.random() < 0.6 else bytearray(bytes(b"ACGT"[k] for k in rng.integers(0, 4, m)))
+        for k in range(len(y)):  # a mutated copy: long diagonal runs, ties, gaps
+            if rng.random() < 0.15:
+                y[k] = b"ACGT"[int(rng.integers(0, 4))]
+        out.append((x, bytes(y)))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["global", "local", "fitting", "overlap"])
+def test_wide_kernels_scores_outside_the_packed_encodings(mode):
+    # inputs the reference computes (align.go:76 takes any int, align_affine.go:12 any float64) and the fast kernels'
+    # encodings cannot hold -- +-300 scores, a gap of 200, gap open 150, affine scores beyond 2^22 -- run on the wide
+    # kernels (kernels_wide.hip): scores and both traces equal the oracle's
+    pairs = _wide_pairs(11)
+    xs, ys = [p[0] for p in pairs], [p[1] for p in pairs]
+    for (ma, mi, go, ge) in [(300, -300, 1, 1), (1, -1, 200, 200), (300, -250, 400, 400), (5, -4, 150, 2), (300, -300, 500, 7),
+                             (90_000, -70_000, 100_000, 30_000)]:
+        a, oa = _Big(ma, mi), O.MatchAligner(ma, mi)
+        if go == ge:
+            sc, t1, t2 = bio_amd.AlignPairBatch(mode, xs, ys, a, go)
+            want = [O.AlignPair(mode, x, y, oa, go) for x, y in pairs]
+        else:
+            sc, t1, t2 = bio_amd.AlignAffineBatch(mode, xs, ys, a, go, ge)
+            want = [O.AlignAffine(mode, x, y, oa, go, ge) for x, y in pairs]
+        for p in range(len(pairs)):
+            assert (sc[p], t1[p], t2[p]) == want[p], (mode, ma, mi, go, ge, p)
+
+
+@pytest.mark.parametrize("mode", ["global", "local", "fitting", "overlap"])
+def test_wide_kernels_equal_the_fast_kernels(mode, monkeypatch):
+    # BIOALIGN_WIDE=1 sends ordinary inputs through the wide kernels: same answers as the fast ones, linear and affine
+    s1, o1, s2, o2 = _ragged(500, 77)
+    for go, ge in ((1, 1), (3, 3), (5, 1), (11, 1)):
+        fast = _traces(_batch(mode, s1, o1, s2, o2, go=go, ge=ge))
+        monkeypatch.setenv("BIOALIGN_WIDE", "1")
+        wide = _traces(_batch(mode, s1, o1, s2, o2, go=go, ge=ge))
+        monkeypatch.delenv("BIOALIGN_WIDE")
+        assert wide == fast, (mode, go, ge)
 
 
 def test_share_pack_between_modes():
