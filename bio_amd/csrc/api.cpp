@@ -488,6 +488,10 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
                              (long long)wabs, (unsigned long long)max_n, (unsigned long long)max_m);
         if (pl->ops)
             return ctx->fail(BIOALIGN_EUNSUPPORTED, "BIOALIGN_TRACE_OPS: not with scores that need the wide kernels");
+        // one lane walks a pair's whole matrix, a byte per cell and lane: fine for reads, not for one huge pair
+        if (max_n * max_m > (1ull << 26))
+            return ctx->fail(BIOALIGN_EUNSUPPORTED, "a pair of %llu x %llu with scores or penalties outside the fast batch kernels' "
+                             "range: use bioalign_long for long pairs", (unsigned long long)max_n, (unsigned long long)max_m);
         pl->wide = true;
         pl->nib = 0;
         pl->fkey = 0;

@@ -606,7 +606,9 @@ __global__ void __launch_bounds__(256) ba_trace_affine_kernel(BaTraceParams P)
     enum { LV_MM = 0, LV_G1 = 1, LV_G2 = 2 };
     int level = LV_MM;
     bool done = !live || (i == 0 && j == 0);
-    while (__any(!done)) {
+    // (every round takes a lane one row or one column closer to the top left corner: n + m rounds at most; the bound
+    // only matters if the decision words were ever wrong -- the walk then ends instead of running off the matrix)
+    for (int guard = n + m + 2; guard > 0 && __any(!done); --guard) {
         if (!done) {
             if (level == LV_MM) {
                 // back-pointer of the middle level (oracle: bmm)

@@ -147,10 +147,13 @@ def test_align_global_affine_score_is_the_references():
         assert isinstance(sc, float)
         assert sc == O.AffineGlobalScoreF64(x, y, O.Blosum62(), go, ge)
         assert bytes(b for b in t1 if b != ord("-")) == x and bytes(b for b in t2 if b != ord("-")) == y
-    # a fraction whose unit makes the scores outgrow the int8 profile is refused by the library, not rounded
-    with pytest.raises(bio_amd._native.BioAlignError) as e:
-        bio_amd.AlignGlobalAffine(b"ACDDE", b"ACE", bio_amd.Blosum62, 1.015625, 0.5)
-    assert e.value.code == bio_amd._native.EUNSUPPORTED
+    # a fraction whose unit makes the scores outgrow the int8 profile runs on the wide (int32) kernels, exactly
+    sc, t1, t2 = bio_amd.AlignGlobalAffine(b"ACDDE", b"ACE", bio_amd.Blosum62, 1.015625, 0.5)
+    assert sc == O.AffineGlobalScoreF64(b"ACDDE", b"ACE", O.Blosum62(), 1.015625, 0.5)
+    assert t1.replace(b"-", b"") == b"ACDDE" and t2.replace(b"-", b"") == b"ACE"
+    # a fraction that is no multiple of 1/64 is refused by the host side, not rounded
+    with pytest.raises(ValueError):
+        bio_amd.AlignGlobalAffine(b"ACDDE", b"ACE", bio_amd.Blosum62, 0.1, 0.5)
     # the input on which the reference's own traceback goes wrong: score as written, trace correct
     sc, t1, t2 = bio_amd.AlignGlobalAffine(b"ACDDE", b"ACE", bio_amd.Blosum62, 5, 1)
     assert sc == O.AffineGlobalScoreF64(b"ACDDE", b"ACE", O.Blosum62(), 5.0, 1.0)

@@ -101,9 +101,14 @@ def test_single_pair_entry_points_route_long_pairs():
     assert bio_amd.AlignGlobal(x, y, a, 1) == O.AlignGlobal(x, y, oa, 1)
     assert bio_amd.AlignLocal(x, y, a, 1) == O.AlignLocal(x, y, oa, 1)
     assert bio_amd.AlignPair("fitting", x, y, a, 1) == O.AlignPair("fitting", x, y, oa, 1)
-    big = bio_amd.MatchAligner(100, -100)  # the long kernels refuse these scores, the call falls back to the batch
-    with pytest.raises(bio_amd._native.BioAlignError):  # kernels, and their refusal is the error that reaches the caller
+    # the long kernels refuse these scores and the call falls back to the batch entry point, whose wide (int32) kernels
+    # hold them up to 2^26 cells a pair; beyond that the refusal is the error that reaches the caller
+    big, obig = bio_amd.MatchAligner(100, -100), O.MatchAligner(100, -100)
+    assert bio_amd.AlignGlobal(x, y, big, 20) == O.AlignGlobal(x, y, obig, 20)
+    x, y = _pair(8300, 8200, 92)
+    with pytest.raises(bio_amd._native.BioAlignError) as e:
         bio_amd.AlignGlobal(x, y, big, 20)
+    assert e.value.code == bio_amd._native.EUNSUPPORTED
 
 
 def test_long_unsupported_fails_loudly():
