@@ -4,7 +4,7 @@ ARCH ?= gfx950
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 CSRC := bio_amd/csrc
 LIB := bio_amd/lib/libbioalign.so
-OBJS := build/kernels.o build/kernels_affine.o build/kernels_long.o build/kernels_fasta.o build/kernels_wide.o build/api.o
+OBJS := build/kernels.o build/kernels_affine.o build/kernels_long.o build/kernels_fasta.o build/kernels_wide.o build/kernels_bp.o build/api.o
 
 all: $(LIB) oracle tests/cpp/bio_test
 
@@ -25,6 +25,10 @@ build/kernels_long.o: $(CSRC)/kernels_long.hip $(CSRC)/common.h $(CSRC)/device_h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 build/kernels_wide.o: $(CSRC)/kernels_wide.hip $(CSRC)/common.h $(CSRC)/device_helpers.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+build/kernels_bp.o: $(CSRC)/kernels_bp.hip $(CSRC)/common.h $(CSRC)/device_helpers.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 

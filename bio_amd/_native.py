@@ -39,6 +39,7 @@ EXPORTS = (
     "bioalign_plan_run",
     "bioalign_plan_share_pack",
     "bioalign_plan_dp_ms",
+    "bioalign_plan_kernel",
     "bioalign_run_noalloc",
     "bioalign_ops_capacity",
     "bioalign_expand_ops",
@@ -201,6 +202,8 @@ def lib():
                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.bioalign_run_noalloc.restype = C.c_int
         L.bioalign_run_noalloc.argtypes = [C.c_void_p, C.c_int, C.POINTER(Batch)] + [C.c_void_p] * 9 + [C.c_void_p]
+        L.bioalign_plan_kernel.restype = C.c_char_p
+        L.bioalign_plan_kernel.argtypes = [C.c_void_p]
         L.bioalign_plan_dp_ms.restype = C.c_int
         L.bioalign_plan_dp_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         _lib = L
@@ -423,6 +426,11 @@ class Plan:
         if rc != 0:
             self.engine._raise(rc)
         self._packed_by = packed_by  # keeps it alive
+
+    @property
+    def kernel(self) -> str:
+        """the family of DP kernels the planner chose: linear, bitparallel, affine, wide"""
+        return lib().bioalign_plan_kernel(self._h).decode()
 
     def dp_ms(self):
         """(summed ms, launches) of the DP kernel since the previous call; sync the stream first."""

@@ -37,6 +37,9 @@ extern "C" hipError_t ba_launch_ops_sizes(const uint64_t *t_len, uint64_t n, uin
 extern "C" hipError_t ba_launch_ops_emit(const BaTraceParams &P, hipStream_t st);
 extern "C" size_t ba_dp_affine_lds_bytes(int nb, int nb4, int na_pad, int R, int waves, int nib);
 extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, int waves, int pipe, hipStream_t st);
+extern "C" int ba_bp_max_rows(void);
+extern "C" hipError_t ba_launch_dp_bp(const BaDpParams &P, int max_words, hipStream_t st);
+extern "C" hipError_t ba_launch_trace_bp(const BaTraceParams &P, hipStream_t st);
 extern "C" hipError_t ba_launch_dp_wide(const BaDpParams &P, int mode, int affine, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_wide(const BaTraceParams &P, int mode, int affine, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_affine(const BaTraceParams &P, int mode, int R, hipStream_t st);
@@ -184,6 +187,7 @@ struct bioalign_plan {
     int nib = 0, kappa = 0;  // affine, large alphabets: 4-bit strip profile (kernels_affine.hip)
     int fkey = 0;            // affine local: float-built best-cell keys (kernels_affine.hip)
     int max_n = 0, max_m = 0;  // longest s1 / s2 of the batch
+    int bp_words = 0;   // > 0: unit scoring (+1 / -1 / gap 1), global: the bit-parallel kernels over this many words of rows (kernels_bp.hip)
     bool wide = false;  // scores or penalties the packed encodings of the fast kernels cannot hold: 32-bit kernels (kernels_wide.hip)
     uint64_t cells = 0;
     std::vector<BaBundle> bundles;
@@ -497,8 +501,18 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         pl->fkey = 0;
         if (!pl->affine) pl->K = 8;
     }
+    // Unit scoring -- every substitution score +1 or -1, gap 1: BASELINE's DNA configuration -- in global mode with
+    // at most four column symbols and rows that fit eight words runs BIT-PARALLEL (kernels_bp.hip): same packed words,
+    // same two bits per cell of traceback matrix, same records.  BIOALIGN_BITPARALLEL=0 keeps the general kernels.
+    if (!wide && !pl->affine && pl->mode == BIOALIGN_GLOBAL && pl->gap == 1 && pl->nb <= 4 && wmax == 1 &&
+        max_n <= (uint64_t)ba_bp_max_rows() && env_u64("BIOALIGN_BITPARALLEL", 1) != 0) {
+        bool unit = true;
+        for (int i = 0; i < pl->na * pl->nb && unit; ++i) unit = in->score_table[i] == 1 || in->score_table[i] == -1;
+        if (unit) pl->bp_words = std::max<int>(1, (int)((max_n + 31) / 32));
+    }
     // strip height and block shape: the strip profile (nb * R bytes per lane) lives in LDS
     pl->R = (pl->nb <= 6 && pl->K <= 4) ? 32 : 16;
+    if (pl->bp_words) pl->R = 32;  // (K = 2 and nb <= 4 already say so: the words of rows are the 32-row strips)
     if (pl->wide) pl->R = 32;  // (only the packing's row padding depends on it)
     if (const uint64_t rows = env_u64("BIOALIGN_STRIP_ROWS", 0)) {  // experiments: 16 where 32 would be chosen
         if (rows == 16) pl->R = 16;
@@ -834,7 +848,9 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             if (timed) HIP_TRY(ctx, hipEventRecord(pl->ev0[pl->ev_used], st));
             dp.table = pl->d_table;
             dp.wide_rows = pl->R;
-            if (pl->wide)
+            if (pl->bp_words)
+                HIP_TRY(ctx, ba_launch_dp_bp(dp, pl->bp_words, st));
+            else if (pl->wide)
                 HIP_TRY(ctx, ba_launch_dp_wide(dp, pl->mode, pl->affine ? 1 : 0, st));
             else if (pl->affine)
                 HIP_TRY(ctx, ba_launch_dp_affine(dp, pl->mode, pl->R, pl->waves, pl->pipe, st));
@@ -891,10 +907,18 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             } else if (pl->affine) {
                 HIP_TRY(ctx, ba_launch_trace_affine(tr, pl->mode, pl->R, ts));
             } else if (!pl->dense) {
-                HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 3, ts));
+                if (pl->bp_words) {
+                    HIP_TRY(ctx, ba_launch_trace_bp(tr, ts));
+                    HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 2, ts));
+                } else {
+                    HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 3, ts));
+                }
             } else {
                 // walk -> prefix sums of the lengths in pair order -> expansion to the dense places
-                HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 1, ts));
+                if (pl->bp_words)
+                    HIP_TRY(ctx, ba_launch_trace_bp(tr, ts));
+                else
+                    HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 1, ts));
                 const uint64_t nparts = (pl->n_pairs + 2047) / 2048;
                 // what is laid back to back: the traces themselves, or (BIOALIGN_TRACE_OPS) the compact records
                 const uint64_t *lens = d_t_len;
@@ -964,6 +988,12 @@ extern "C" int bioalign_plan_dp_ms(bioalign_plan *pl, float *ms, int *n_launches
     if (n_launches) *n_launches = (int)pl->ev_used;
     pl->ev_used = 0;
     return 0;
+}
+
+extern "C" const char *bioalign_plan_kernel(const bioalign_plan *pl)
+{
+    if (!pl) return "";
+    return pl->bp_words ? "bitparallel" : pl->wide ? "wide" : pl->affine ? "affine" : "linear";
 }
 
 // The allocation-free variant of bioalign_plan_create + bioalign_plan_run (include/bioalign.h): the same planner and

@@ -28,6 +28,13 @@ __device__ __forceinline__ uint32_t ba_push_residue(uint32_t acc, int x)
     return __builtin_amdgcn_alignbit((uint32_t)x, acc, K);
 }
 
+// One record of the linear-gap walks (kernels.hip, kernels_bp.hip): 16 moves, 2 bits each (first move in the low
+// bits), and the cell the first of them starts from.  ba_expand_kernel turns the records into the two gapped strings.
+struct BaMoveRec {
+    uint32_t ops, i, j, count;
+};
+enum { BA_MV_UP = 0, BA_MV_LEFT = 1, BA_MV_DIAG = 2 };
+
 // ----------------------------------------------------------------------------
 // strip profile: prof[b][half][lane][16 rows] = score(row r of the strip, column symbol b), int8,
 // built from the transposed table wt[c][a] (dwords of 4 column symbols) in LDS.

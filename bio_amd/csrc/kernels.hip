@@ -400,12 +400,7 @@ struct BaTraceGeom {
     static constexpr int WORDS = 2 * BW;       // LDS words per lane (two bands)
 };
 
-// One record of the walk: 16 moves, 2 bits each (first move in the low bits), and the cell
-// the first of them starts from.
-struct BaMoveRec {
-    uint32_t ops, i, j, count;
-};
-enum { BA_MV_UP = 0, BA_MV_LEFT = 1, BA_MV_DIAG = 2 };
+// (BaMoveRec, the record of 16 moves the walk writes, is in device_helpers.h: the bit-parallel walk writes them too)
 
 // The walk only records its moves (BaMoveRec per 16 moves); ba_expand_kernel turns them into
 // bytes with one thread per record -- no symbol load, no byte shuffling and no scattered store

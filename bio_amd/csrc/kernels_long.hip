@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
 // (2) The EXPANSION of the move codes into the two gapped byte strings (align.go:126-143;
 // align_pair.go:197-216) is a prefix sum: one block, 1024 threads.
 // ----------------------------------------------------------------------------
-enum { BA_MV_UP = 0, BA_MV_LEFT = 1, BA_MV_DIAG = 2 };
+// (BA_MV_UP / LEFT / DIAG: device_helpers.h)
 
 // Local mode: the end cell is the first maximum in row-major order (align.go:216-221).  The DP left the largest
 // score of every lane's T rows (lane_max, in row order); this kernel finds the maximum M and the first lane group that

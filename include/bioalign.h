@@ -365,6 +365,14 @@ int bioalign_run_noalloc(bioalign_ctx *ctx, int device_index, const bioalign_bat
  */
 int bioalign_plan_dp_ms(bioalign_plan *plan, float *ms, int *n_launches);
 
+/*
+ * Which family of DP kernels the planner chose for this plan (no counterpart
+ * in the reference; for benchmarks and tests): "linear", "bitparallel" (unit
+ * scoring +1 / -1 / gap 1 in global mode: AlignGlobal, align.go:76), "affine"
+ * or "wide".  A static string.
+ */
+const char *bioalign_plan_kernel(const bioalign_plan *plan);
+
 #ifdef __cplusplus
 }
 #endif

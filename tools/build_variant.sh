@@ -10,7 +10,7 @@ src=bio_amd/csrc/$file.hip; x=""
 if [ "$file" = api ]; then src=bio_amd/csrc/api.cpp; x="-x hip"; fi
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $flags $x -c -o build/ab/$name.o $src
 objs=""
-for o in kernels kernels_affine kernels_long kernels_fasta kernels_wide api; do
+for o in kernels kernels_affine kernels_long kernels_fasta kernels_wide kernels_bp api; do
   if [ "$o" = "$file" ]; then objs="$objs build/ab/$name.o"; else objs="$objs build/$o.o"; fi
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o bio_amd/lib/$name.so $objs
