@@ -38,8 +38,9 @@ extern "C" hipError_t ba_launch_ops_emit(const BaTraceParams &P, hipStream_t st)
 extern "C" size_t ba_dp_affine_lds_bytes(int nb, int nb4, int na_pad, int R, int waves, int nib);
 extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, int waves, int pipe, hipStream_t st);
 extern "C" int ba_bp_max_rows(void);
-extern "C" hipError_t ba_launch_dp_bp(const BaDpParams &P, int max_words, hipStream_t st);
-extern "C" hipError_t ba_launch_trace_bp(const BaTraceParams &P, hipStream_t st);
+extern "C" int ba_bp_max_local_score(void);
+extern "C" hipError_t ba_launch_dp_bp(const BaDpParams &P, int mode, int max_words, hipStream_t st);
+extern "C" hipError_t ba_launch_trace_bp(const BaTraceParams &P, int mode, hipStream_t st);
 extern "C" hipError_t ba_launch_dp_wide(const BaDpParams &P, int mode, int affine, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_wide(const BaTraceParams &P, int mode, int affine, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_affine(const BaTraceParams &P, int mode, int R, hipStream_t st);
@@ -501,11 +502,13 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         pl->fkey = 0;
         if (!pl->affine) pl->K = 8;
     }
-    // Unit scoring -- every substitution score +1 or -1, gap 1: BASELINE's DNA configuration -- in global mode with
+    // Unit scoring -- every substitution score +1 or -1, gap 1: BASELINE's DNA configuration -- in global or local mode with
     // at most four column symbols and rows that fit eight words runs BIT-PARALLEL (kernels_bp.hip): same packed words,
     // same two bits per cell of traceback matrix, same records.  BIOALIGN_BITPARALLEL=0 keeps the general kernels.
-    if (!wide && !pl->affine && pl->mode == BIOALIGN_GLOBAL && pl->gap == 1 && pl->nb <= 4 && wmax == 1 &&
-        max_n <= (uint64_t)ba_bp_max_rows() && env_u64("BIOALIGN_BITPARALLEL", 1) != 0) {
+    // (local mode keeps the scores bit-sliced in eight planes: no alignment can score above min(len(s1), len(s2)))
+    if (!wide && !pl->affine && pl->gap == 1 && pl->nb <= 4 && wmax == 1 && max_n <= (uint64_t)ba_bp_max_rows() &&
+        (pl->mode == BIOALIGN_GLOBAL || (pl->mode == BIOALIGN_LOCAL && min_nm_max <= (uint64_t)ba_bp_max_local_score())) &&
+        env_u64("BIOALIGN_BITPARALLEL", 1) != 0) {
         bool unit = true;
         for (int i = 0; i < pl->na * pl->nb && unit; ++i) unit = in->score_table[i] == 1 || in->score_table[i] == -1;
         if (unit) pl->bp_words = std::max<int>(1, (int)((max_n + 31) / 32));
@@ -849,7 +852,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             dp.table = pl->d_table;
             dp.wide_rows = pl->R;
             if (pl->bp_words)
-                HIP_TRY(ctx, ba_launch_dp_bp(dp, pl->bp_words, st));
+                HIP_TRY(ctx, ba_launch_dp_bp(dp, pl->mode, pl->bp_words, st));
             else if (pl->wide)
                 HIP_TRY(ctx, ba_launch_dp_wide(dp, pl->mode, pl->affine ? 1 : 0, st));
             else if (pl->affine)
@@ -908,7 +911,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
                 HIP_TRY(ctx, ba_launch_trace_affine(tr, pl->mode, pl->R, ts));
             } else if (!pl->dense) {
                 if (pl->bp_words) {
-                    HIP_TRY(ctx, ba_launch_trace_bp(tr, ts));
+                    HIP_TRY(ctx, ba_launch_trace_bp(tr, pl->mode, ts));
                     HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 2, ts));
                 } else {
                     HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 3, ts));
@@ -916,7 +919,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             } else {
                 // walk -> prefix sums of the lengths in pair order -> expansion to the dense places
                 if (pl->bp_words)
-                    HIP_TRY(ctx, ba_launch_trace_bp(tr, ts));
+                    HIP_TRY(ctx, ba_launch_trace_bp(tr, pl->mode, ts));
                 else
                     HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 1, ts));
                 const uint64_t nparts = (pl->n_pairs + 2047) / 2048;

@@ -38,23 +38,16 @@
 #include "device_helpers.h"
 #include "bp_column.h"
 
-#define BA_BP_MAX_WORDS 8  // rows <= 256
+#define BA_BP_MAX_WORDS 8   // rows <= 256
+#define BA_BP_SCORE_BITS 8  // local mode: bit-sliced scores, so min(len(s1), len(s2)) <= 255
 
 // ----------------------------------------------------------------------------
 // DP
 // ----------------------------------------------------------------------------
+// match vectors of the lane's s1 against every column symbol: peq[(b * WW + w) * 64]
 template <int WW>
-__device__ __forceinline__ void ba_bp_bundle(const BaDpParams &P, const BaBundle &B, uint32_t *peq, const uint8_t *mm,
-                                             const uint8_t *code2, int lane)
+__device__ __forceinline__ void ba_bp_build_peq(const uint32_t *s1w, const uint8_t *mm, int front, uint32_t *peq)
 {
-    const int n = (int)B.n, m = (int)B.m;
-    const int front = WW * 32 - n;  // 0..31
-    const int cgs = (m + 3) / 4;
-    const uint32_t *s1w = P.s1w + B.s1w_off + lane;
-    const uint32_t *s2w = P.s2w + B.s2w_off + lane;
-    uint32_t *dir = P.dir + B.dir_off + (size_t)lane * 4;
-
-    // match vectors of the lane's s1 against every column symbol: peq[(b * WW + w) * 64]
 #pragma unroll
     for (int w = 0; w < WW; ++w) {
         uint32_t pl[4] = {0u, 0u, 0u, 0u};
@@ -73,6 +66,20 @@ __device__ __forceinline__ void ba_bp_bundle(const BaDpParams &P, const BaBundle
 #pragma unroll
         for (int b = 0; b < 4; ++b) peq[(b * WW + w) * 64] = pl[b] & keep;
     }
+}
+
+template <int WW>
+__device__ __forceinline__ void ba_bp_bundle(const BaDpParams &P, const BaBundle &B, uint32_t *peq, const uint8_t *mm,
+                                             const uint8_t *code2, int lane)
+{
+    const int n = (int)B.n, m = (int)B.m;
+    const int front = WW * 32 - n;  // 0..31
+    const int cgs = (m + 3) / 4;
+    const uint32_t *s1w = P.s1w + B.s1w_off + lane;
+    const uint32_t *s2w = P.s2w + B.s2w_off + lane;
+    uint32_t *dir = P.dir + B.dir_off + (size_t)lane * 4;
+
+    ba_bp_build_peq<WW>(s1w, mm, front, peq);
 
     // column 0: dV = gap in every row (x = 0); the rows above the matrix hold x = 1 for ever and hand h = 0 -- the top
     // border's dH = gap (align.go:92-95) -- down to row 1
@@ -133,6 +140,101 @@ __device__ __forceinline__ void ba_bp_bundle(const BaDpParams &P, const BaBundle
     }
 }
 
+// LOCAL mode (align.go:152-249): bp_column.h's ba_bp_local_column; the end cell is tracked column by column.
+template <int WW>
+__device__ __forceinline__ void ba_bp_local_bundle(const BaDpParams &P, const BaBundle &B, uint32_t *peq, const uint8_t *mm,
+                                                   const uint8_t *code2, int lane)
+{
+    constexpr int NB = BA_BP_SCORE_BITS;
+    const int n = (int)B.n, m = (int)B.m;
+    const int front = WW * 32 - n;  // 0..31
+    const int cgs = (m + 3) / 4;
+    const uint32_t *s1w = P.s1w + B.s1w_off + lane;
+    const uint32_t *s2w = P.s2w + B.s2w_off + lane;
+    uint32_t *dir = P.dir + B.dir_off + (size_t)lane * 4;
+    ba_bp_build_peq<WW>(s1w, mm, front, peq);
+
+    // column 0: H = 0 in every row, so dV = 0 (x = 1)
+    uint32_t V1[WW], V2[WW], V3[WW], Zr[WW], H[NB][WW];
+#pragma unroll
+    for (int w = 0; w < WW; ++w) {
+        V1[w] = Zr[w] = 0xffffffffu;
+        V2[w] = V3[w] = 0u;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) H[k][w] = 0u;
+    }
+    // the maximum so far and its first cell in row-major order (align.go:214-221), row counted over the padded rows
+    int best = 0, best_t = 0, best_j = 0;
+
+    uint32_t accA[4][WW], accB[4][WW];
+    auto column_group = [&](int cg, uint32_t sw, auto full) {
+        constexpr bool FULL = decltype(full)::value;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (FULL || cg * 4 + c < m) {
+                const uint32_t b = (uint32_t)code2[(sw >> (8 * c)) & 0xffu] & 3u;
+                const uint32_t *pq = peq + b * (WW * 64);
+                uint32_t M[WW], S[NB], T[NB], gt[WW], eq[WW];
+#pragma unroll
+                for (int w = 0; w < WW; ++w) M[w] = pq[w * 64];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    S[k] = 0u - (((uint32_t)best >> k) & 1u);
+                    T[k] = 0u - (((uint32_t)(best + 1) >> k) & 1u);
+                }
+                ba_bp_local_column<WW, NB>(V1, V2, V3, H, Zr, M, S, T, accA[c], accB[c], gt, eq);
+                // Within a column the maximum grows by at most 1.  A row above it (gt): the new maximum, first cell =
+                // the lowest such row of this column.  Otherwise a row AT it (eq) in a higher row than the cell held
+                // so far comes first in row-major order.  (best = 0: nothing is held; every empty cell "equals" it.)
+                uint32_t og = gt[0];
+#pragma unroll
+                for (int w = 1; w < WW; ++w) og |= gt[w];
+                const bool grew = og != 0u;
+                int r = 0x7fffffff;
+#pragma unroll
+                for (int w = WW - 1; w >= 0; --w) {
+                    const uint32_t cand = grew ? gt[w] : eq[w];
+                    if (cand) r = 32 * w + (int)__builtin_ctz(cand);
+                }
+                const bool take = grew || (best > 0 && r < best_t);
+                best += grew ? 1 : 0;
+                best_t = take ? r : best_t;
+                best_j = take ? cg * 4 + c + 1 : best_j;
+            } else {
+#pragma unroll
+                for (int w = 0; w < WW; ++w) accA[c][w] = accB[c][w] = 0u;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < WW; ++w) {
+            *reinterpret_cast<uint4 *>(dir + ((size_t)(w * 2 + 0) * cgs + cg) * 256) =
+                make_uint4(accA[0][w], accA[1][w], accA[2][w], accA[3][w]);
+            *reinterpret_cast<uint4 *>(dir + ((size_t)(w * 2 + 1) * cgs + cg) * 256) =
+                make_uint4(accB[0][w], accB[1][w], accB[2][w], accB[3][w]);
+        }
+    };
+    if (cgs > 0) {
+        const int full_groups = m / 4;
+        uint32_t nxt = s2w[0];
+        asm volatile("" : "+v"(nxt));
+        for (int cg = 0; cg < full_groups; ++cg) {
+            const uint32_t cur = nxt;
+            nxt = s2w[(size_t)min(cg + 1, cgs - 1) * 64];
+            column_group(cg, cur, std::true_type{});
+        }
+        if (full_groups < cgs) column_group(full_groups, nxt, std::false_type{});
+    }
+    if (lane < (int)B.count) {
+        BaLocalBest bb;
+        bb.score = best;
+        bb.i = best > 0 ? best_t - front + 1 : 0;
+        bb.j = best > 0 ? best_j : 0;
+        bb.pad = 0;
+        P.best[B.first + lane] = bb;
+    }
+}
+
+template <int MODE>
 __global__ void __launch_bounds__(256) ba_dp_bp_kernel(BaDpParams P, int max_words)
 {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -156,27 +258,34 @@ __global__ void __launch_bounds__(256) ba_dp_bp_kernel(BaDpParams P, int max_wor
     const BaBundle B = P.bundles[b_idx];
     uint32_t *peq = lds + 128 + (size_t)wave * (4 * max_words * 64) + lane;
     const int words = ((int)B.n + 31) / 32;
-    switch (words) {
-    case 0:  // no rows: S(0, m) = -m; the walk goes left along the top border
+    if (words == 0) {  // no rows: global S(0, m) = -m, the walk goes left along the top border; local: the empty alignment
         if (lane < (int)B.count) {
             BaLocalBest bb;
-            bb.score = -(int)B.m;
+            bb.score = MODE == BA_LOCAL ? 0 : -(int)B.m;
             bb.i = 0;
-            bb.j = (int)B.m;
+            bb.j = MODE == BA_LOCAL ? 0 : (int)B.m;
             bb.pad = 0;
             P.best[B.first + lane] = bb;
         }
+        return;
+    }
+#define BA_BP_CASE(W)                                                                   \
+    case W:                                                                             \
+        if (MODE == BA_LOCAL) ba_bp_local_bundle<W>(P, B, peq, mm, code2, lane);        \
+        else ba_bp_bundle<W>(P, B, peq, mm, code2, lane);                               \
         break;
-    case 1: ba_bp_bundle<1>(P, B, peq, mm, code2, lane); break;
-    case 2: ba_bp_bundle<2>(P, B, peq, mm, code2, lane); break;
-    case 3: ba_bp_bundle<3>(P, B, peq, mm, code2, lane); break;
-    case 4: ba_bp_bundle<4>(P, B, peq, mm, code2, lane); break;
-    case 5: ba_bp_bundle<5>(P, B, peq, mm, code2, lane); break;
-    case 6: ba_bp_bundle<6>(P, B, peq, mm, code2, lane); break;
-    case 7: ba_bp_bundle<7>(P, B, peq, mm, code2, lane); break;
-    case 8: ba_bp_bundle<8>(P, B, peq, mm, code2, lane); break;
+    switch (words) {
+        BA_BP_CASE(1)
+        BA_BP_CASE(2)
+        BA_BP_CASE(3)
+        BA_BP_CASE(4)
+        BA_BP_CASE(5)
+        BA_BP_CASE(6)
+        BA_BP_CASE(7)
+        BA_BP_CASE(8)
     default: break;  // (the planner never sends longer rows here)
     }
+#undef BA_BP_CASE
 }
 
 // ----------------------------------------------------------------------------
@@ -187,6 +296,7 @@ __global__ void __launch_bounds__(256) ba_dp_bp_kernel(BaDpParams P, int max_wor
 // ----------------------------------------------------------------------------
 #define BA_BP_BG 6  // column groups per band (24 columns: a diagonal through 32 rows reloads once)
 
+template <bool LOCAL>
 __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
 {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -209,7 +319,7 @@ __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
     int i = 0, j = 0;
     if (live) {
         const BaLocalBest bb = P.best[B.first + lane];
-        i = bb.i;  // (n, m): align.go:123-124
+        i = bb.i;  // global: (n, m), align.go:123-124; local: the first maximum in row-major order, (0, 0) if there is none
         j = bb.j;
         P.scores[p] = (int64_t)bb.score;
         if (P.score_only && P.t_off) {  // BIOALIGN_END_CELLS
@@ -269,13 +379,14 @@ __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
     // load per word and lane, all lanes' loads in flight at once); inside a word every lane takes one move per round
     // until all have left it upwards.  The round is branch-free but for the record that fills up every 16 moves:
     // `bit` is the lane's row inside the word, `idx` its column inside the band.
+    bool done = false;  // local: the walk has reached a cell with H = 0 (or a border, where H = 0 too)
     for (int w = (n + front - 1) >> 5; w >= 0 && n > 0; --w) {
         const int lo_i = max(32 * w + 1 - front, 1);  // first row of the word; a lane is in it while i >= lo_i
         uint32_t bit = 1u << ((uint32_t)(i - 1 + front) & 31u);
         if (i >= lo_i && j >= 1) col0 = load_band(w, j - 1);
         int idx = j - 1 - col0;
         while (true) {
-            const bool act = i >= lo_i;
+            const bool act = i >= lo_i && !done;
             if (!__any(act)) break;
             if (__any(act && j >= 1 && idx < 0)) {  // (a lane has walked out of its band on the left)
                 if (act && j >= 1 && idx < 0) {
@@ -284,24 +395,31 @@ __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
                 }
             }
             if (act) {
-                const int ix = max(idx, 0);  // (j == 0: nothing to look up -- the left border's moves are forced, align.go:99-100)
+                const int ix = max(idx, 0);  // (j == 0: nothing to look up)
                 const uint32_t a = band[ix * 64], b = band[(BW + ix) * 64];
-                // align.go:105-116: up unless left is strictly better, left unless the diagonal is
-                const bool up = (a & bit) == 0u || j == 0, left = (b & bit) == 0u;
-                const uint32_t mv = up ? BA_MV_UP : left ? BA_MV_LEFT : BA_MV_DIAG;
-                opw |= mv << sh;
-                sh += 2;
-                const int di = mv != BA_MV_LEFT, dj = mv != BA_MV_UP;
-                i -= di;
-                j -= dj;
-                idx -= dj;
-                bit >>= di;
-                if (sh == 32) flush();
+                const bool abit = (a & bit) != 0u, bbit = (b & bit) != 0u;
+                // align.go:105-116 / 186-202: up unless left is strictly better, left unless the diagonal is
+                uint32_t mv = !abit ? BA_MV_UP : !bbit ? BA_MV_LEFT : BA_MV_DIAG;
+                bool stop = false;
+                if (LOCAL) stop = j == 0 || (!abit && bbit);  // (0, 1): H = 0; column 0: H = 0
+                else if (j == 0) mv = BA_MV_UP;               // global: the left border's moves are forced (align.go:99-100)
+                if (stop) {
+                    done = true;
+                } else {
+                    opw |= mv << sh;
+                    sh += 2;
+                    const int di = mv != BA_MV_LEFT, dj = mv != BA_MV_UP;
+                    i -= di;
+                    j -= dj;
+                    idx -= dj;
+                    bit >>= di;
+                    if (sh == 32) flush();
+                }
             }
         }
     }
-    // row 0: left along the top border
-    while (__any(j > 0)) {
+    // row 0: global walks left along the top border; local stops there (H = 0)
+    while (!LOCAL && __any(j > 0)) {
         if (j > 0) {
             opw |= (uint32_t)BA_MV_LEFT << sh;
             sh += 2;
@@ -330,28 +448,41 @@ __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
 // host-side launchers (called from api.cpp)
 // ----------------------------------------------------------------------------
 extern "C" int ba_bp_max_rows(void) { return BA_BP_MAX_WORDS * 32; }
+extern "C" int ba_bp_max_local_score(void) { return (1 << BA_BP_SCORE_BITS) - 1; }
 
 extern "C" size_t ba_dp_bp_lds_bytes(int max_words, int waves) { return 512 + (size_t)waves * 4 * max_words * 64 * 4; }
 
-extern "C" hipError_t ba_launch_dp_bp(const BaDpParams &P, int max_words, hipStream_t st)
+extern "C" hipError_t ba_launch_dp_bp(const BaDpParams &P, int mode, int max_words, hipStream_t st)
 {
     const uint32_t nbundles = P.bundle_end - P.bundle_begin;
     if (nbundles == 0) return hipSuccess;
     if (max_words < 1 || max_words > BA_BP_MAX_WORDS || P.nb > 4 || !P.table) return hipErrorInvalidValue;
     const int waves = 4;
-    hipLaunchKernelGGL(ba_dp_bp_kernel, dim3((nbundles + waves - 1) / waves), dim3(waves * 64),
-                       ba_dp_bp_lds_bytes(max_words, waves), st, P, max_words);
+    const dim3 grid((nbundles + waves - 1) / waves), block(waves * 64);
+    const size_t lds = ba_dp_bp_lds_bytes(max_words, waves);
+    if (mode == BA_GLOBAL)
+        hipLaunchKernelGGL(ba_dp_bp_kernel<BA_GLOBAL>, grid, block, lds, st, P, max_words);
+    else if (mode == BA_LOCAL)
+        hipLaunchKernelGGL(ba_dp_bp_kernel<BA_LOCAL>, grid, block, lds, st, P, max_words);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 // the walk only (scores, move records, lengths); the expansion is ba_launch_trace_linear's phase 2
-extern "C" hipError_t ba_launch_trace_bp(const BaTraceParams &P, hipStream_t st)
+extern "C" hipError_t ba_launch_trace_bp(const BaTraceParams &P, int mode, hipStream_t st)
 {
     const uint32_t nbundles = P.bundle_end - P.bundle_begin;
     if (nbundles == 0) return hipSuccess;
     if (!P.score_only && !P.rec) return hipErrorInvalidValue;
     const int waves = 4;
-    hipLaunchKernelGGL(ba_trace_bp_kernel, dim3((nbundles + waves - 1) / waves), dim3(waves * 64),
-                       (size_t)waves * 2 * BA_BP_BG * 4 * 64 * 4, st, P);
+    const dim3 grid((nbundles + waves - 1) / waves), block(waves * 64);
+    const size_t lds = (size_t)waves * 2 * BA_BP_BG * 4 * 64 * 4;
+    if (mode == BA_GLOBAL)
+        hipLaunchKernelGGL(ba_trace_bp_kernel<false>, grid, block, lds, st, P);
+    else if (mode == BA_LOCAL)
+        hipLaunchKernelGGL(ba_trace_bp_kernel<true>, grid, block, lds, st, P);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }

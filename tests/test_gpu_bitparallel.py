@@ -1,5 +1,5 @@
-"""The bit-parallel kernels (bio_amd/csrc/kernels_bp.hip: unit scoring +1 / -1 / gap 1, global mode) against the
-oracle (align.go:76-143), bit for bit on scores and both traces, and against the general kernels."""
+"""The bit-parallel kernels (bio_amd/csrc/kernels_bp.hip: unit scoring +1 / -1 / gap 1, global and local mode) against
+the oracle (align.go:76-143, 152-249), bit for bit on scores and both traces, and against the general kernels."""
 import random
 
 import numpy as np
@@ -28,11 +28,15 @@ def _plan_kernel(s1s, s2s, aligner, gap, mode="global"):
     return k
 
 
-def _check(s1s, s2s, pa, oa, gap=1):
-    scores, t1s, t2s = bio_amd.AlignPairBatch("global", s1s, s2s, pa, gap)
+MODES = ("global", "local")
+A, OA = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
+
+
+def _check(mode, s1s, s2s, pa=A, oa=OA, gap=1):
+    scores, t1s, t2s = bio_amd.AlignPairBatch(mode, s1s, s2s, pa, gap)
     for p, (x, y) in enumerate(zip(s1s, s2s)):
-        want = O.AlignPair("global", x, y, oa, gap)
-        assert (scores[p], t1s[p], t2s[p]) == want, (p, x, y)
+        want = O.AlignPair(mode, x, y, oa, gap)
+        assert (scores[p], t1s[p], t2s[p]) == want, (mode, p, x, y)
 
 
 def _rand(rnd, n, al=b"ACGT"):
@@ -55,7 +59,10 @@ def test_which_plans_run_bit_parallel(monkeypatch):
     a = bio_amd.MatchAligner(1, -1)
     x = [b"ACGTACGTAC" * 15] * 3
     assert _plan_kernel(x, x, a, 1) == "bitparallel"
-    assert _plan_kernel(x, x, a, 1, mode="local") == "linear"
+    assert _plan_kernel(x, x, a, 1, mode="local") == "bitparallel"
+    assert _plan_kernel(x, x, a, 1, mode="fitting") == "linear"
+    assert _plan_kernel([b"ACGT" * 64], [b"ACGT" * 64], a, 1, mode="local") == "linear"  # a local score of 256 needs nine bits
+    assert _plan_kernel([b"ACGT" * 64], [b"ACGT" * 63], a, 1, mode="local") == "bitparallel"
     assert _plan_kernel(x, x, a, 2) == "linear"
     assert _plan_kernel(x, x, bio_amd.MatchAligner(1, -2), 1) == "linear"
     assert _plan_kernel([b"ACGT" * 65], [b"ACGT"], a, 1) == "linear"  # 260 rows: more than eight words
@@ -66,16 +73,18 @@ def test_which_plans_run_bit_parallel(monkeypatch):
     assert _plan_kernel(x, x, a, 1) == "linear"
 
 
-def test_config1_shape_150bp():
+@pytest.mark.parametrize("mode", MODES)
+def test_config1_shape_150bp(mode):
     # BASELINE configs[1]'s pair shape: 150 x 150, five words of rows, ten padded rows above the matrix
     s1, o1, s2, o2 = synth.dna_pairs(200, 150, 150, config=2)
     s1s = [bytes(s1[int(o1[p]):int(o1[p + 1])]) for p in range(200)]
     s2s = [bytes(s2[int(o2[p]):int(o2[p + 1])]) for p in range(200)]
-    assert _plan_kernel(s1s, s2s, bio_amd.MatchAligner(1, -1), 1) == "bitparallel"
-    _check(s1s, s2s, bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1))
+    assert _plan_kernel(s1s, s2s, A, 1, mode=mode) == "bitparallel"
+    _check(mode, s1s, s2s)
 
 
-def test_every_row_count_and_ragged_columns():
+@pytest.mark.parametrize("mode", MODES)
+def test_every_row_count_and_ragged_columns(mode):
     # every number of rows 0..256 (all word counts, all paddings) against columns of every length modulo 4, related
     # and unrelated sequences, in one ragged batch: bundles of every word count in one launch
     rnd = random.Random(11)
@@ -83,43 +92,67 @@ def test_every_row_count_and_ragged_columns():
     for n in range(0, 257):
         x = _rand(rnd, n)
         s1s.append(x)
-        s2s.append(_edited(rnd, x) if n % 3 else _rand(rnd, rnd.randint(0, 270)))
-    assert _plan_kernel(s1s, s2s, bio_amd.MatchAligner(1, -1), 1) == "bitparallel"
-    _check(s1s, s2s, bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1))
+        s2s.append(_edited(rnd, x)[:255] if n % 3 else _rand(rnd, rnd.randint(0, 255)))
+    assert _plan_kernel(s1s, s2s, A, 1, mode=mode) == "bitparallel"
+    _check(mode, s1s, s2s)
 
 
-def test_empty_sides_and_single_cells():
+@pytest.mark.parametrize("mode", MODES)
+def test_empty_sides_and_single_cells(mode):
     cases = [(b"", b""), (b"A", b""), (b"", b"C"), (b"A", b"A"), (b"A", b"C"), (b"ACGT", b""), (b"", b"ACGT" * 40),
-             (b"A" * 256, b"A"), (b"A", b"A" * 300), (b"ACGT" * 64, b"ACGT" * 64), (b"A" * 33, b"C" * 31)]
+             (b"A" * 256, b"A"), (b"A", b"A" * 300), (b"ACGT" * 64, b"ACGT" * 63), (b"A" * 33, b"C" * 31),
+             (b"A" * 255, b"A" * 255), (b"ACGT" * 50, b"TGCA" * 50), (b"C" * 200, b"A" * 100 + b"C" + b"A" * 100)]
     s1s, s2s = [c[0] for c in cases], [c[1] for c in cases]
-    _check(s1s, s2s, bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1))
+    assert _plan_kernel(s1s, s2s, A, 1, mode=mode) == "bitparallel"
+    _check(mode, s1s, s2s)
 
 
-def test_low_complexity_ties():
+def test_local_end_cell_is_the_first_maximum_in_row_major_order():
+    # several cells hold the maximum: the end cell is the first of them by rows, then by columns (align.go:214-221) --
+    # repeats put equal maxima in the same row, in higher rows of later columns and in lower rows of earlier ones
+    rnd = random.Random(9)
+    s1s, s2s = [], []
+    core = b"GATTACA"
+    for k in range(120):
+        junk = lambda q: bytes(rnd.choice(b"CT") for _ in range(q))
+        x = junk(rnd.randint(0, 30)) + core + junk(rnd.randint(0, 30)) + (core if k % 2 else b"") + junk(rnd.randint(0, 20))
+        y = junk(rnd.randint(0, 30)) + core + junk(rnd.randint(0, 40)) + (core if k % 3 else b"") + junk(rnd.randint(0, 20))
+        s1s.append(x)
+        s2s.append(y)
+    s1s += [b"ACAC" * 30, b"A" * 100, b"AC" * 50, b"TTTT"]
+    s2s += [b"ACAC" * 30, b"A" * 57, b"CA" * 41, b"AAAA"]
+    assert _plan_kernel(s1s, s2s, A, 1, mode="local") == "bitparallel"
+    _check("local", s1s, s2s)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_low_complexity_ties(mode):
     # two-letter and one-letter sequences: nearly every cell is a tie, the candidate order decides the trace
     rnd = random.Random(5)
     s1s = [_rand(rnd, rnd.randint(1, 200), b"AC") for _ in range(150)] + [b"A" * k for k in range(1, 40)]
     s2s = [_rand(rnd, rnd.randint(1, 200), b"AC") for _ in range(150)] + [b"A" * (40 - k) for k in range(1, 40)]
-    _check(s1s, s2s, bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1))
+    _check(mode, s1s, s2s)
 
 
-def test_full_bundles_equal_the_general_kernels(monkeypatch):
+@pytest.mark.parametrize("mode", MODES)
+def test_full_bundles_equal_the_general_kernels(monkeypatch, mode):
     # several full bundles (64 pairs a wavefront, four wavefronts a block) of one shape; strings, scores, and the
     # general kernels' output on the same batch
     rnd = random.Random(3)
     s1s = [_rand(rnd, 97) for _ in range(700)]
     s2s = [_edited(rnd, x)[:110] for x in s1s]
-    a = bio_amd.MatchAligner(1, -1)
-    got = bio_amd.AlignPairBatch("global", s1s, s2s, a, 1)
+    got = bio_amd.AlignPairBatch(mode, s1s, s2s, A, 1)
     monkeypatch.setenv("BIOALIGN_BITPARALLEL", "0")
-    ref = bio_amd.AlignPairBatch("global", s1s, s2s, a, 1)
+    ref = bio_amd.AlignPairBatch(mode, s1s, s2s, A, 1)
     assert list(got[0]) == list(ref[0]) and got[1] == ref[1] and got[2] == ref[2]
     for p in range(0, 700, 37):
-        assert (got[0][p], got[1][p], got[2][p]) == O.AlignPair("global", s1s[p], s2s[p], O.MatchAligner(1, -1), 1)
+        assert (got[0][p], got[1][p], got[2][p]) == O.AlignPair(mode, s1s[p], s2s[p], OA, 1)
 
 
 def test_single_pair_entry_point_and_scores_only():
     x, y = b"GATTACAGATTACA" * 9, b"GATACAGGATTAC" * 9
     assert bio_amd.AlignGlobal(x, y, bio_amd.MatchAligner(1, -1), 1) == O.AlignGlobal(x, y, O.MatchAligner(1, -1), 1)
-    sc = bio_amd.AlignPairBatch("global", [x, y], [y, x], bio_amd.MatchAligner(1, -1), 1, score_only=True)
-    assert list(sc[0]) == [O.AlignGlobal(x, y, O.MatchAligner(1, -1), 1)[0], O.AlignGlobal(y, x, O.MatchAligner(1, -1), 1)[0]]
+    assert bio_amd.AlignLocal(x, y, A, 1) == O.AlignLocal(x, y, OA, 1)
+    for mode in MODES:
+        sc = bio_amd.AlignPairBatch(mode, [x, y], [y, x], A, 1, score_only=True)
+        assert list(sc[0]) == [O.AlignPair(mode, x, y, OA, 1)[0], O.AlignPair(mode, y, x, OA, 1)[0]]

@@ -112,6 +112,10 @@ __global__ void __launch_bounds__(256) op_kernel(int *out, int seed, unsigned lo
             if (OP == 80) OPK("v_dot4c_i32_i8 %0, %1, %2\n");
             if (OP == 81) OPK("v_pk_fma_f16 %0, %0, %1, %2");
             if (OP == 82) OPK("v_add_f16 %0, %0, %1");
+            if (OP == 83) OPK("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x36");
+            if (OP == 84) OPK("v_not_b32 %0, %1");
+            if (OP == 85) OPK("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x30");
+            if (OP == 86) OPK("v_ffbl_b32 %0, %1");
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -129,7 +133,7 @@ static const char *NAMES[] = {"v_add_u32", "v_max_i32", "v_max3_i32", "v_cmp_gt_
     "v_cmp_gt_i32+v_addc_co_u32 (pair)", "v_xor_b32", "v_min_i32",
     "v_dot4_i32_i8", "v_dot4c_i32_i8", "v_sub_co_u32", "v_add_u16", "v_sub_u16", "v_max_u16", "v_min_i16", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_or_b32", "v_lshl_or_b32", "v_and_or_b32", "v_bfi_b32", "v_sub_u32 clamp", "v_mad_u32_u24", "v_mul_u32_u24", "v_mad_u16", "v_alignbyte_b32", "v_add_u16_sdwa(sext byte)", "v_max_i16_sdwa(word1)", "v_add_u32 dpp wave_shr", "v_mov_b32 dpp wave_shr", "v_bcnt_u32_b32", "v_sad_u8", "v_pk_mad_u16", "v_pk_lshrrev_b16", "v_cvt_f32_i32", "v_min3_i32", "v_add_co_u32", "v_sub_u32 sdwa sext byte", "v_mad_i32_i24",
     "v_sub_f32 clamp (e64)", "v_fmac_f32 x2.0", "v_pk_add_f32 neg clamp", "v_pk_fma_f32", "v_add_u32_sdwa + v_fmac_f32 (pair)", "v_bfe_i32 + v_add_u32 + v_fmac_f32 (triple)", "v_add_u32_sdwa + v_max_i32 (pair)", "v_sub_f32 clamp + v_fmac_f32 (pair)",
-    "v_cvt_f32_ubyte1", "v_sub_f16 clamp (e64)", "v_fma_f16", "v_madmk_f16", "v_fma_mix_f32", "v_fma_f16 op_sel hi", "v_cvt_f32_ubyte1 + v_add_f32 (pair)", "v_max_f16 + v_sub_f16 clamp (pair)", "v_dot4c_i32_i8 again", "v_pk_fma_f16", "v_add_f16"};
+    "v_cvt_f32_ubyte1", "v_sub_f16 clamp (e64)", "v_fma_f16", "v_madmk_f16", "v_fma_mix_f32", "v_fma_f16 op_sel hi", "v_cvt_f32_ubyte1 + v_add_f32 (pair)", "v_max_f16 + v_sub_f16 clamp (pair)", "v_dot4c_i32_i8 again", "v_pk_fma_f16", "v_add_f16", "v_bitop3_b32 (3 sources)", "v_not_b32", "v_bitop3_b32 (2 sources)", "v_ffbl_b32"};
 
 template <int OP>
 void run(int *d_out, unsigned long long *d_clk, int cus, int waves_per_simd)
@@ -165,7 +169,7 @@ template <int OP>
 void run_all(int *d_out, unsigned long long *d_clk, int cus)
 {
     run<OP>(d_out, d_clk, cus, 8);
-    if constexpr (OP + 1 < 83) run_all<OP + 1>(d_out, d_clk, cus);
+    if constexpr (OP + 1 < 87) run_all<OP + 1>(d_out, d_clk, cus);
 }
 
 int main()
@@ -177,7 +181,7 @@ int main()
     CHECK(hipMalloc(&d_out, (size_t)prop.multiProcessorCount * 8 * 256 * sizeof(int)));
     CHECK(hipMalloc(&d_clk, 16));
     if (getenv("VALU_OPS_FROM")) {  // only the newer cases
-        run_all<72>(d_out, d_clk, prop.multiProcessorCount);
+        run_all<83>(d_out, d_clk, prop.multiProcessorCount);
         return 0;
     }
     run_all<0>(d_out, d_clk, prop.multiProcessorCount);
