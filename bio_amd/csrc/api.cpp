@@ -40,7 +40,7 @@ extern "C" hipError_t ba_launch_dp_affine(const BaDpParams &P, int mode, int R, 
 extern "C" int ba_bp_max_rows(void);
 extern "C" int ba_bp_max_local_score(void);
 extern "C" hipError_t ba_launch_dp_bp(const BaDpParams &P, int mode, int max_words, hipStream_t st);
-extern "C" hipError_t ba_launch_trace_bp(const BaTraceParams &P, int mode, hipStream_t st);
+extern "C" hipError_t ba_launch_trace_bp(const BaTraceParams &P, int mode, int max_words, hipStream_t st);
 extern "C" hipError_t ba_launch_dp_wide(const BaDpParams &P, int mode, int affine, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_wide(const BaTraceParams &P, int mode, int affine, hipStream_t st);
 extern "C" hipError_t ba_launch_trace_affine(const BaTraceParams &P, int mode, int R, hipStream_t st);
@@ -911,7 +911,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
                 HIP_TRY(ctx, ba_launch_trace_affine(tr, pl->mode, pl->R, ts));
             } else if (!pl->dense) {
                 if (pl->bp_words) {
-                    HIP_TRY(ctx, ba_launch_trace_bp(tr, pl->mode, ts));
+                    HIP_TRY(ctx, ba_launch_trace_bp(tr, pl->mode, pl->bp_words, ts));
                     HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 2, ts));
                 } else {
                     HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 3, ts));
@@ -919,7 +919,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             } else {
                 // walk -> prefix sums of the lengths in pair order -> expansion to the dense places
                 if (pl->bp_words)
-                    HIP_TRY(ctx, ba_launch_trace_bp(tr, pl->mode, ts));
+                    HIP_TRY(ctx, ba_launch_trace_bp(tr, pl->mode, pl->bp_words, ts));
                 else
                     HIP_TRY(ctx, ba_launch_trace_linear(tr, pl->mode, pl->R, pl->K, 1, ts));
                 const uint64_t nparts = (pl->n_pairs + 2047) / 2048;

@@ -68,18 +68,31 @@ __device__ __forceinline__ void ba_bp_build_peq(const uint32_t *s1w, const uint8
     }
 }
 
-template <int WW>
+// GLOBAL mode.  The DP stores no traceback matrix: every CKPT columns it leaves the three planes of the column state
+// (a CHECKPOINT: 3 bits per row), and the lane's match vectors once; the walk recomputes the columns between two
+// checkpoints in registers with the same column function and decides its moves from them (ba_bp_walk_bundle).  The
+// kernel was bound by its 2 bits per cell of stores (5.6 GB per launch at 1M x 150 x 150); a column costs a fifth of
+// the time those bytes took.  Layout per bundle in the direction-word buffer (dwords, lane-interleaved):
+//     [4 symbols][WW words][64 lanes] match vectors, then [block][3 planes][WW words][64 lanes] checkpoints,
+// block b = the state BEFORE column b * CKPT + 1.
+template <int WW, int CKPT>
 __device__ __forceinline__ void ba_bp_bundle(const BaDpParams &P, const BaBundle &B, uint32_t *peq, const uint8_t *mm,
                                              const uint8_t *code2, int lane)
 {
+    static_assert(CKPT == 4 || CKPT == 8, "checkpoints every 4 or 8 columns");
     const int n = (int)B.n, m = (int)B.m;
     const int front = WW * 32 - n;  // 0..31
     const int cgs = (m + 3) / 4;
     const uint32_t *s1w = P.s1w + B.s1w_off + lane;
     const uint32_t *s2w = P.s2w + B.s2w_off + lane;
-    uint32_t *dir = P.dir + B.dir_off + (size_t)lane * 4;
+    uint32_t *ck = P.dir + B.dir_off + lane;
+    uint32_t *cs = ck + 4 * WW * 64;
 
     ba_bp_build_peq<WW>(s1w, mm, front, peq);
+    if (m > 0) {  // (no columns: the buffer has no room and the walk no use for them)
+#pragma unroll
+        for (int k = 0; k < 4 * WW; ++k) ck[k * 64] = peq[k * 64];
+    }
 
     // column 0: dV = gap in every row (x = 0); the rows above the matrix hold x = 1 for ever and hand h = 0 -- the top
     // border's dH = gap (align.go:92-95) -- down to row 1
@@ -88,31 +101,27 @@ __device__ __forceinline__ void ba_bp_bundle(const BaDpParams &P, const BaBundle
     for (int w = 0; w < WW; ++w) V1[w] = V2[w] = V3[w] = 0u;
     V1[0] = (1u << front) - 1u;
 
-    uint32_t accV[4][WW], accP[4][WW];
     auto column_group = [&](int cg, uint32_t sw, auto full) {
         constexpr bool FULL = decltype(full)::value;
+        if ((cg * 4) % CKPT == 0) {
+            uint32_t *c0 = cs + (size_t)((cg * 4) / CKPT) * (3 * WW * 64);
+#pragma unroll
+            for (int w = 0; w < WW; ++w) {
+                c0[(0 * WW + w) * 64] = V1[w];
+                c0[(1 * WW + w) * 64] = V2[w];
+                c0[(2 * WW + w) * 64] = V3[w];
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (FULL || cg * 4 + c < m) {
                 const uint32_t b = (uint32_t)code2[(sw >> (8 * c)) & 0xffu] & 3u;
                 const uint32_t *pq = peq + b * (WW * 64);
-                uint32_t M[WW];
+                uint32_t M[WW], oP[WW];
 #pragma unroll
                 for (int w = 0; w < WW; ++w) M[w] = pq[w * 64];
-                ba_bp_column<WW>(V1, V2, V3, M, accP[c]);
-#pragma unroll
-                for (int w = 0; w < WW; ++w) accV[c][w] = V1[w];
-            } else {
-#pragma unroll
-                for (int w = 0; w < WW; ++w) accV[c][w] = accP[c][w] = 0u;
+                ba_bp_column<WW>(V1, V2, V3, M, oP);
             }
-        }
-#pragma unroll
-        for (int w = 0; w < WW; ++w) {
-            *reinterpret_cast<uint4 *>(dir + ((size_t)(w * 2 + 0) * cgs + cg) * 256) =
-                make_uint4(accV[0][w], accV[1][w], accV[2][w], accV[3][w]);
-            *reinterpret_cast<uint4 *>(dir + ((size_t)(w * 2 + 1) * cgs + cg) * 256) =
-                make_uint4(accP[0][w], accP[1][w], accP[2][w], accP[3][w]);
         }
     };
     if (cgs > 0) {
@@ -234,7 +243,7 @@ __device__ __forceinline__ void ba_bp_local_bundle(const BaDpParams &P, const Ba
     }
 }
 
-template <int MODE>
+template <int MODE, int CKPT>
 __global__ void __launch_bounds__(256) ba_dp_bp_kernel(BaDpParams P, int max_words)
 {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -269,10 +278,10 @@ __global__ void __launch_bounds__(256) ba_dp_bp_kernel(BaDpParams P, int max_wor
         }
         return;
     }
-#define BA_BP_CASE(W)                                                                   \
-    case W:                                                                             \
-        if (MODE == BA_LOCAL) ba_bp_local_bundle<W>(P, B, peq, mm, code2, lane);        \
-        else ba_bp_bundle<W>(P, B, peq, mm, code2, lane);                               \
+#define BA_BP_CASE(W)                                                                              \
+    case W:                                                                                        \
+        if constexpr (MODE == BA_LOCAL) ba_bp_local_bundle<W>(P, B, peq, mm, code2, lane);         \
+        else if constexpr (W <= 5 || CKPT == 4) ba_bp_bundle<W, CKPT>(P, B, peq, mm, code2, lane); \
         break;
     switch (words) {
         BA_BP_CASE(1)
@@ -445,12 +454,224 @@ __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
 }
 
 // ----------------------------------------------------------------------------
+// traceback, GLOBAL mode: recompute and walk.  The wavefront goes over the blocks of CKPT columns from the last to
+// the first, all lanes together (every global path crosses every column): a block's columns are recomputed from
+// its checkpoint into registers -- two planes per column, [dV' >= 1] and [dH' >= 1] -- and then walked right to
+// left.  In a column a lane first takes its up moves (a run of zero bits of the first plane below its row: one
+// count-leading-zeros), then one left or diagonal move into the column before.  Nothing but the checkpoints
+// (3 bits per row every CKPT columns) and the match vectors is read.
+// ----------------------------------------------------------------------------
+template <int WW>
+__device__ __forceinline__ uint32_t ba_bp_pick(const uint32_t (&a)[WW], int w)
+{
+    // (masks and v_bitop3, not a chain of selects: hipcc turns the chain into an indexed load from scratch memory
+    // and the block's planes then live there)
+    uint32_t v = 0u;
+#pragma unroll
+    for (int k = 0; k < WW; ++k) v = ba_bitop3<(BA_TA & BA_TB) | BA_TC>(a[k], (w == k) ? 0xffffffffu : 0u, v);
+    return v;
+}
+
+template <int WW, int CKPT>
+__device__ __forceinline__ uint32_t ba_bp_walk_bundle(const BaTraceParams &P, const BaBundle &B, uint32_t *peq,
+                                                      const uint8_t *code2, int lane, bool live)
+{
+    const int n = (int)B.n, m = (int)B.m;
+    const int front = WW * 32 - n;
+    const int cgs = (m + 3) / 4;
+    const int nblk = (m + CKPT - 1) / CKPT;
+    const uint32_t *ck = P.dir + B.dir_off + lane;
+    const uint32_t *cs = ck + 4 * WW * 64;
+    const uint32_t *s2w = P.s2w + B.s2w_off + lane;
+    if (m > 0) {
+#pragma unroll
+        for (int k = 0; k < 4 * WW; ++k) peq[k * 64] = ck[k * 64];
+    }
+    int i = live ? n : 0;  // the row the lane is in; its column is the wavefront's
+    BaMoveRec *recs = reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap + 1;
+    uint32_t opw = 0, sh = 0, nrec = 0;
+    // closes the record: `ci`, `cj` is the cell its last move arrived in
+    auto flush = [&](int ci, int cj) __attribute__((always_inline)) {
+        const uint32_t count = sh >> 1;
+        const uint32_t valid = count >= 16 ? 0xffffffffu : ((1u << sh) - 1u);
+        const uint32_t lo = opw & 0x55555555u, hi = (opw >> 1) & 0x55555555u;
+        const uint32_t n_left = __popc(lo & ~hi & valid), n_up = __popc(~lo & ~hi & 0x55555555u & valid);
+        BaMoveRec rr;
+        rr.ops = opw;
+        rr.i = (uint32_t)ci + count - n_left;
+        rr.j = (uint32_t)cj + count - n_up;
+        rr.count = count;
+        if (live) recs[nrec] = rr;
+        ++nrec;
+        opw = 0;
+        sh = 0;
+    };
+    auto ups = [&](int k, int cj) __attribute__((always_inline)) {  // k up moves in column cj (code 0: only the position advances)
+        while (k > 0) {
+            const int take = min(k, (int)((32u - sh) >> 1));
+            sh += 2u * (uint32_t)take;
+            i -= take;
+            k -= take;
+            if (sh == 32) flush(i, cj);
+        }
+    };
+    for (int blk = nblk - 1; blk >= 0; --blk) {
+        const int j0 = blk * CKPT, cols = min(CKPT, m - j0);
+        uint32_t V1[WW], V2[WW], V3[WW];
+        const uint32_t *c0 = cs + (size_t)blk * (3 * WW * 64);
+#pragma unroll
+        for (int w = 0; w < WW; ++w) {
+            V1[w] = c0[(0 * WW + w) * 64];
+            V2[w] = c0[(1 * WW + w) * 64];
+            V3[w] = c0[(2 * WW + w) * 64];
+        }
+        uint32_t sw[CKPT / 4];
+#pragma unroll
+        for (int q = 0; q < CKPT / 4; ++q) sw[q] = s2w[(size_t)min(j0 / 4 + q, cgs - 1) * 64];
+        uint32_t oV[CKPT][WW], oP[CKPT][WW];
+#pragma unroll
+        for (int c = 0; c < CKPT; ++c) {
+            if (c < cols) {
+                const uint32_t b = (uint32_t)code2[(sw[c / 4] >> (8 * (c % 4))) & 0xffu] & 3u;
+                const uint32_t *pq = peq + b * (WW * 64);
+                uint32_t M[WW];
+#pragma unroll
+                for (int w = 0; w < WW; ++w) M[w] = pq[w * 64];
+                ba_bp_column<WW>(V1, V2, V3, M, oP[c]);
+#pragma unroll
+                for (int w = 0; w < WW; ++w) oV[c][w] = V1[w];
+            }
+        }
+        // (one instance per column, spelled out: left as a loop around the run loop below, hipcc keeps it rolled
+        // and the block's planes, indexed by the loop counter, go to scratch memory)
+        auto walk_column = [&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value;
+            if (c < cols) {
+                const int j = j0 + c + 1;
+                // up while the cell came from above (align.go:105-108: the first candidate wins ties)
+                while (i > 0) {
+                    const int t = i - 1 + front;
+                    const uint32_t f = (uint32_t)t & 31u;
+                    const uint32_t x = ba_bp_pick<WW>(oV[c], t >> 5) << (31u - f);  // my row's bit on top, the rows above it below
+                    const int run = x ? __clz(x) : (int)f + 1;
+                    if (run == 0) break;
+                    ups(run, j);
+                    if (x) break;  // (else the run goes on in the word above)
+                }
+                if (i == 0) {  // top border: left (align.go:92-95)
+                    opw |= (uint32_t)BA_MV_LEFT << sh;
+                } else {
+                    const int t = i - 1 + front;
+                    const uint32_t pw = ba_bp_pick<WW>(oP[c], t >> 5);
+                    const uint32_t diag = (pw >> ((uint32_t)t & 31u)) & 1u;  // left unless the diagonal is strictly better
+                    opw |= (diag ? (uint32_t)BA_MV_DIAG : (uint32_t)BA_MV_LEFT) << sh;
+                    i -= (int)diag;
+                }
+                sh += 2;
+                if (sh == 32) flush(i, j - 1);
+            }
+        };
+        if constexpr (CKPT == 8) {
+            walk_column(std::integral_constant<int, 7>{});
+            walk_column(std::integral_constant<int, 6>{});
+            walk_column(std::integral_constant<int, 5>{});
+            walk_column(std::integral_constant<int, 4>{});
+        }
+        walk_column(std::integral_constant<int, 3>{});
+        walk_column(std::integral_constant<int, 2>{});
+        walk_column(std::integral_constant<int, 1>{});
+        walk_column(std::integral_constant<int, 0>{});
+    }
+    ups(i, 0);  // left border: up (align.go:99-100)
+    const uint32_t len = nrec * 16 + (sh >> 1);
+    if (sh) flush(0, 0);
+    return len;
+}
+
+template <int CKPT>
+__global__ void __launch_bounds__(256) ba_trace_bp_ckpt_kernel(BaTraceParams P, int max_words)
+{
+    extern __shared__ __align__(16) uint32_t lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves = blockDim.x >> 6;
+    uint8_t *code2 = reinterpret_cast<uint8_t *>(lds) + 256;  // (same places as in the DP kernel)
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) code2[k] = P.code2[k];
+    __syncthreads();
+    const uint32_t b_idx = P.bundle_begin + blockIdx.x * waves + wave;
+    if (b_idx >= P.bundle_end) return;
+    const BaBundle B = P.bundles[b_idx];
+    const bool live = lane < (int)B.count;
+    const uint32_t p = live ? P.perm[B.first + lane] : 0u;
+    const int n = (int)B.n, m = (int)B.m;
+    if (live) {
+        const BaLocalBest bb = P.best[B.first + lane];
+        P.scores[p] = (int64_t)bb.score;
+        if (P.score_only && P.t_off) {  // BIOALIGN_END_CELLS: (n, m), align.go:123-124
+            P.t_off[p] = (uint64_t)bb.i;
+            P.t_len[p] = (uint64_t)bb.j;
+        }
+    }
+    if (P.score_only) return;
+    uint32_t *peq = lds + 128 + (size_t)wave * (4 * max_words * 64) + lane;
+    const int words = (n + 31) / 32;
+    uint32_t len = 0;
+#define BA_BP_CASE(W)                                                                                          \
+    case W:                                                                                                    \
+        if constexpr (W <= 5 || CKPT == 4) len = ba_bp_walk_bundle<W, CKPT>(P, B, peq, code2, lane, live);     \
+        break;
+    switch (words) {
+    case 0: {  // no rows: m left moves along the top border
+        BaMoveRec *recs = reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap + 1;
+        for (int k = 0; k < m; k += 16) {
+            const int count = min(16, m - k);
+            BaMoveRec rr;
+            rr.ops = 0x55555555u & (count >= 16 ? 0xffffffffu : ((1u << (2 * count)) - 1u));
+            rr.i = 0;
+            rr.j = (uint32_t)(m - k);
+            rr.count = (uint32_t)count;
+            if (live) recs[k / 16] = rr;
+        }
+        len = (uint32_t)m;
+        break;
+    }
+        BA_BP_CASE(1)
+        BA_BP_CASE(2)
+        BA_BP_CASE(3)
+        BA_BP_CASE(4)
+        BA_BP_CASE(5)
+        BA_BP_CASE(6)
+        BA_BP_CASE(7)
+        BA_BP_CASE(8)
+    default: break;
+    }
+#undef BA_BP_CASE
+    if (!live) return;
+    // where the trace ends inside the pair's slot (as kernels.hip's walk places it)
+    const uint64_t slot = P.s1_off[p] + P.s2_off[p];
+    const uint64_t cap = (uint64_t)n + (uint64_t)m;
+    const uint64_t mis = ((uint64_t)P.t1 + slot + cap) & 15u;
+    const uint64_t end = (mis + len <= cap) ? slot + cap - mis : slot + cap;
+    P.t_off[p] = end - len;
+    P.t_len[p] = len;
+    BaMoveRec hd;
+    hd.ops = len;
+    hd.i = (uint32_t)end;
+    hd.j = (uint32_t)(end >> 32);
+    hd.count = p;
+    (reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap)[0] = hd;
+}
+
+// ----------------------------------------------------------------------------
 // host-side launchers (called from api.cpp)
 // ----------------------------------------------------------------------------
 extern "C" int ba_bp_max_rows(void) { return BA_BP_MAX_WORDS * 32; }
 extern "C" int ba_bp_max_local_score(void) { return (1 << BA_BP_SCORE_BITS) - 1; }
 
 extern "C" size_t ba_dp_bp_lds_bytes(int max_words, int waves) { return 512 + (size_t)waves * 4 * max_words * 64 * 4; }
+
+// checkpoints every 8 columns where the rows fit five words (the walk holds a block's planes in registers)
+static inline int ba_bp_ckpt(int max_words) { return max_words <= 5 ? 8 : 4; }
 
 extern "C" hipError_t ba_launch_dp_bp(const BaDpParams &P, int mode, int max_words, hipStream_t st)
 {
@@ -460,29 +681,36 @@ extern "C" hipError_t ba_launch_dp_bp(const BaDpParams &P, int mode, int max_wor
     const int waves = 4;
     const dim3 grid((nbundles + waves - 1) / waves), block(waves * 64);
     const size_t lds = ba_dp_bp_lds_bytes(max_words, waves);
-    if (mode == BA_GLOBAL)
-        hipLaunchKernelGGL(ba_dp_bp_kernel<BA_GLOBAL>, grid, block, lds, st, P, max_words);
+    if (mode == BA_GLOBAL && ba_bp_ckpt(max_words) == 8)
+        hipLaunchKernelGGL((ba_dp_bp_kernel<BA_GLOBAL, 8>), grid, block, lds, st, P, max_words);
+    else if (mode == BA_GLOBAL)
+        hipLaunchKernelGGL((ba_dp_bp_kernel<BA_GLOBAL, 4>), grid, block, lds, st, P, max_words);
     else if (mode == BA_LOCAL)
-        hipLaunchKernelGGL(ba_dp_bp_kernel<BA_LOCAL>, grid, block, lds, st, P, max_words);
+        hipLaunchKernelGGL((ba_dp_bp_kernel<BA_LOCAL, 4>), grid, block, lds, st, P, max_words);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 // the walk only (scores, move records, lengths); the expansion is ba_launch_trace_linear's phase 2
-extern "C" hipError_t ba_launch_trace_bp(const BaTraceParams &P, int mode, hipStream_t st)
+extern "C" hipError_t ba_launch_trace_bp(const BaTraceParams &P, int mode, int max_words, hipStream_t st)
 {
     const uint32_t nbundles = P.bundle_end - P.bundle_begin;
     if (nbundles == 0) return hipSuccess;
     if (!P.score_only && !P.rec) return hipErrorInvalidValue;
+    if (max_words < 1 || max_words > BA_BP_MAX_WORDS) return hipErrorInvalidValue;
     const int waves = 4;
     const dim3 grid((nbundles + waves - 1) / waves), block(waves * 64);
-    const size_t lds = (size_t)waves * 2 * BA_BP_BG * 4 * 64 * 4;
-    if (mode == BA_GLOBAL)
-        hipLaunchKernelGGL(ba_trace_bp_kernel<false>, grid, block, lds, st, P);
-    else if (mode == BA_LOCAL)
-        hipLaunchKernelGGL(ba_trace_bp_kernel<true>, grid, block, lds, st, P);
-    else
+    if (mode == BA_GLOBAL) {
+        const size_t lds = ba_dp_bp_lds_bytes(max_words, waves);
+        if (ba_bp_ckpt(max_words) == 8)
+            hipLaunchKernelGGL(ba_trace_bp_ckpt_kernel<8>, grid, block, lds, st, P, max_words);
+        else
+            hipLaunchKernelGGL(ba_trace_bp_ckpt_kernel<4>, grid, block, lds, st, P, max_words);
+    } else if (mode == BA_LOCAL) {
+        hipLaunchKernelGGL(ba_trace_bp_kernel<true>, grid, block, (size_t)waves * 2 * BA_BP_BG * 4 * 64 * 4, st, P);
+    } else {
         return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
