@@ -243,8 +243,11 @@ __device__ __forceinline__ void ba_bp_local_bundle(const BaDpParams &P, const Ba
     }
 }
 
-template <int MODE, int CKPT>
-__global__ void __launch_bounds__(256) ba_dp_bp_kernel(BaDpParams P, int max_words)
+// WMAX: the longest rows (in words) this instance takes -- its registers are those of its largest bundle shape
+// (local, five words: 168 VGPRs = three wavefronts per SIMD, with one 8-byte spill per column group)
+template <int MODE, int CKPT, int WMAX>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE != BA_LOCAL ? 4 : WMAX <= 3 ? 4 : WMAX <= 5 ? 3 : 2)))
+ba_dp_bp_kernel(BaDpParams P, int max_words)
 {
     extern __shared__ __align__(16) uint32_t lds[];
     const int lane = threadIdx.x & 63;
@@ -280,7 +283,8 @@ __global__ void __launch_bounds__(256) ba_dp_bp_kernel(BaDpParams P, int max_wor
     }
 #define BA_BP_CASE(W)                                                                              \
     case W:                                                                                        \
-        if constexpr (MODE == BA_LOCAL) ba_bp_local_bundle<W>(P, B, peq, mm, code2, lane);         \
+        if constexpr (W > WMAX) break;                                                             \
+        else if constexpr (MODE == BA_LOCAL) ba_bp_local_bundle<W>(P, B, peq, mm, code2, lane);    \
         else if constexpr (W <= 5 || CKPT == 4) ba_bp_bundle<W, CKPT>(P, B, peq, mm, code2, lane); \
         break;
     switch (words) {
@@ -303,7 +307,9 @@ __global__ void __launch_bounds__(256) ba_dp_bp_kernel(BaDpParams P, int max_wor
 // (32 rows); per word a lane stages a band of BG column groups of both planes around its column in LDS
 // ([plane][column][lane]: any per-lane index is conflict free) and every step reads the two bits of its own cell.
 // ----------------------------------------------------------------------------
-#define BA_BP_BG 6  // column groups per band (24 columns: a diagonal through 32 rows reloads once)
+#ifndef BA_BP_BG
+#define BA_BP_BG 10  // column groups per band: 40 columns, so that a diagonal through a word's 32 rows needs one load (4 / 6 / 8 / 10 groups: 0.73 / 0.69 / 0.78 / 0.61 ms)
+#endif
 
 template <bool LOCAL>
 __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
@@ -682,11 +688,15 @@ extern "C" hipError_t ba_launch_dp_bp(const BaDpParams &P, int mode, int max_wor
     const dim3 grid((nbundles + waves - 1) / waves), block(waves * 64);
     const size_t lds = ba_dp_bp_lds_bytes(max_words, waves);
     if (mode == BA_GLOBAL && ba_bp_ckpt(max_words) == 8)
-        hipLaunchKernelGGL((ba_dp_bp_kernel<BA_GLOBAL, 8>), grid, block, lds, st, P, max_words);
+        hipLaunchKernelGGL((ba_dp_bp_kernel<BA_GLOBAL, 8, 5>), grid, block, lds, st, P, max_words);
     else if (mode == BA_GLOBAL)
-        hipLaunchKernelGGL((ba_dp_bp_kernel<BA_GLOBAL, 4>), grid, block, lds, st, P, max_words);
+        hipLaunchKernelGGL((ba_dp_bp_kernel<BA_GLOBAL, 4, 8>), grid, block, lds, st, P, max_words);
+    else if (mode == BA_LOCAL && max_words <= 3)
+        hipLaunchKernelGGL((ba_dp_bp_kernel<BA_LOCAL, 4, 3>), grid, block, lds, st, P, max_words);
+    else if (mode == BA_LOCAL && max_words <= 5)
+        hipLaunchKernelGGL((ba_dp_bp_kernel<BA_LOCAL, 4, 5>), grid, block, lds, st, P, max_words);
     else if (mode == BA_LOCAL)
-        hipLaunchKernelGGL((ba_dp_bp_kernel<BA_LOCAL, 4>), grid, block, lds, st, P, max_words);
+        hipLaunchKernelGGL((ba_dp_bp_kernel<BA_LOCAL, 4, 8>), grid, block, lds, st, P, max_words);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
