@@ -38,6 +38,11 @@
 #include "device_helpers.h"
 #include "bp_column.h"
 
+__device__ __forceinline__ void ba_lds_store(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 #define BA_BP_MAX_WORDS 8   // rows <= 256
 #define BA_BP_SCORE_BITS 8  // local mode: bit-sliced scores, so min(len(s1), len(s2)) <= 255
 
@@ -64,7 +69,9 @@ __device__ __forceinline__ void ba_bp_build_peq(const uint32_t *s1w, const uint8
         // rows above the matrix match nothing
         const uint32_t keep = (w == 0) ? (0xffffffffu << front) : 0xffffffffu;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) peq[(b * WW + w) * 64] = pl[b] & keep;
+        // (relaxed workgroup-scope atomic stores stay single ds_write_b32: hipcc pairs plain stores into ds_write2st64_b32
+        // and overwrites a data register in the next instruction -- the pattern tools/scan_ds_write2.py looks for)
+        for (int b = 0; b < 4; ++b) ba_lds_store(peq + (b * WW + w) * 64, pl[b] & keep);
     }
 }
 
@@ -378,14 +385,14 @@ __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
         }
 #pragma unroll
         for (int k = 0; k < BG; ++k) {
-            band[(k * 4 + 0) * 64] = qv[k].x;
-            band[(k * 4 + 1) * 64] = qv[k].y;
-            band[(k * 4 + 2) * 64] = qv[k].z;
-            band[(k * 4 + 3) * 64] = qv[k].w;
-            band[(BW + k * 4 + 0) * 64] = qp[k].x;
-            band[(BW + k * 4 + 1) * 64] = qp[k].y;
-            band[(BW + k * 4 + 2) * 64] = qp[k].z;
-            band[(BW + k * 4 + 3) * 64] = qp[k].w;
+            ba_lds_store(band + (k * 4 + 0) * 64, qv[k].x);
+            ba_lds_store(band + (k * 4 + 1) * 64, qv[k].y);
+            ba_lds_store(band + (k * 4 + 2) * 64, qv[k].z);
+            ba_lds_store(band + (k * 4 + 3) * 64, qv[k].w);
+            ba_lds_store(band + (BW + k * 4 + 0) * 64, qp[k].x);
+            ba_lds_store(band + (BW + k * 4 + 1) * 64, qp[k].y);
+            ba_lds_store(band + (BW + k * 4 + 2) * 64, qp[k].z);
+            ba_lds_store(band + (BW + k * 4 + 3) * 64, qp[k].w);
         }
         return (cg_hi - (BG - 1)) * 4;
     };
@@ -491,7 +498,7 @@ __device__ __forceinline__ uint32_t ba_bp_walk_bundle(const BaTraceParams &P, co
     const uint32_t *s2w = P.s2w + B.s2w_off + lane;
     if (m > 0) {
 #pragma unroll
-        for (int k = 0; k < 4 * WW; ++k) peq[k * 64] = ck[k * 64];
+        for (int k = 0; k < 4 * WW; ++k) ba_lds_store(peq + k * 64, ck[k * 64]);
     }
     int i = live ? n : 0;  // the row the lane is in; its column is the wavefront's
     BaMoveRec *recs = reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap + 1;
