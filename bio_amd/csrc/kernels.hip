@@ -674,7 +674,9 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
 // Expansion of the walk's records into the two gapped byte strings (align.go:126-143, 224-248;
 // align_pair.go:197-216).  One block per bundle, 16 threads per pair, one record (16 trace
 // columns) per thread and round: the symbols a record needs are two short runs of s1 and s2.
-#define BA_EXPAND_TPP 8  // threads per pair
+#ifndef BA_EXPAND_TPP
+#define BA_EXPAND_TPP 4  // threads per pair (2 / 4 / 8 / 16: 0.36 / 0.32 / 0.35 / 0.51 ms per 1M pairs of 150 bp: more, smaller blocks in flight per CU)
+#endif
 __global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_expand_kernel(BaTraceParams P)
 {
     // per thread: the (at most 16, unaligned) bytes of s1 and of s2 its record consumes, as 5 aligned dwords each
@@ -758,7 +760,9 @@ __global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_expand_kernel(BaTracePa
 // `row + index` and threads -- different rows, or the same row sixteen symbols apart -- hardly ever meet in a bank
 // (the per-thread staging of the kernel above conflicted on a fifth of its reads, and its blocks went through four
 // dependent round trips to memory).
-#define BA_EXPAND_PRE 3  // records per thread loaded ahead (3 * 8 * 16 trace columns: pairs of 192 + 192 in one go)
+#ifndef BA_EXPAND_PRE
+#define BA_EXPAND_PRE 3  // records per thread loaded ahead (3 * 4 * 16 trace columns: pairs of 96 + 96 in one go)
+#endif
 extern "C" size_t ba_expand_bundle_lds_bytes(int max_n, int max_m, int R)
 {
     const size_t w1 = (size_t)((max_n + R - 1) / R) * R / 4, w2 = (size_t)(max_m + 3) / 4;
