@@ -571,7 +571,8 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         const uint64_t sz_dir_fast = pl->affine ? strips * ((m + cpw - 1) / cpw) * 64 * 4
                                                 : strips * (uint64_t)((m + 3) / 4) * 64 * chw;
         // (wide: a decision byte per cell and lane; the H row -- and the F row -- of m + 1 scores per lane)
-        const uint64_t sz_dir = pl->wide ? (uint64_t)n * m * 16 + 64 : sz_dir_fast;
+        // (bit-parallel kernels, score-only plans: scores and end cells come out of the DP kernel itself)
+        const uint64_t sz_dir = pl->wide ? (uint64_t)n * m * 16 + 64 : (pl->bp_words && pl->score_only) ? 0 : sz_dir_fast;
         const uint64_t rec_cap = ((uint64_t)n + m) / 16 + 2;  // header + ceil((n + m) / 16) records
         const uint64_t sz_rec = use_rec ? rec_cap * 64 : 0;  // records of 16 bytes
         const uint64_t after = (o_s1w + sz_s1w + o_s2w + sz_s2w + o_hb + sz_hb + o_dir + sz_dir) * 4 + (o_rec + sz_rec) * 16;
@@ -847,6 +848,7 @@ extern "C" int bioalign_plan_run(bioalign_plan *pl, const uint8_t *d_s1, const u
             dp.kappa = pl->kappa;
             dp.fkey = pl->fkey;
             dp.pipe_bundles = (int)env_u64("BIOALIGN_PIPE_BUNDLES", 1);
+            dp.no_dir = (pl->bp_words && pl->score_only) ? 1 : 0;
             const bool timed = pl->ev_used < pl->ev0.size();
             if (timed) HIP_TRY(ctx, hipEventRecord(pl->ev0[pl->ev_used], st));
             dp.table = pl->d_table;

@@ -68,6 +68,7 @@ struct BaDpParams {
     const int32_t *table;  // wide kernels: na * nb scores as the caller gave them (kernels_wide.hip)
     int wide_rows;         // wide kernels: rows per strip of the packed s1 words (their front padding)
     int pipe_bundles;      // affine strip pipeline: bundles a block runs back to back (kernels_affine.hip)
+    int no_dir;            // bit-parallel kernels, score-only plans: nothing is stored for a traceback (`dir` has no room)
 };
 
 struct BaTraceParams {

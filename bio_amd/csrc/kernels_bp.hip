@@ -96,7 +96,7 @@ __device__ __forceinline__ void ba_bp_bundle(const BaDpParams &P, const BaBundle
     uint32_t *cs = ck + 4 * WW * 64;
 
     ba_bp_build_peq<WW>(s1w, mm, front, peq);
-    if (m > 0) {  // (no columns: the buffer has no room and the walk no use for them)
+    if (m > 0 && !P.no_dir) {  // (no columns: the buffer has no room and the walk no use for them)
 #pragma unroll
         for (int k = 0; k < 4 * WW; ++k) ck[k * 64] = peq[k * 64];
     }
@@ -110,7 +110,7 @@ __device__ __forceinline__ void ba_bp_bundle(const BaDpParams &P, const BaBundle
 
     auto column_group = [&](int cg, uint32_t sw, auto full) {
         constexpr bool FULL = decltype(full)::value;
-        if ((cg * 4) % CKPT == 0) {
+        if ((cg * 4) % CKPT == 0 && !P.no_dir) {
             uint32_t *c0 = cs + (size_t)((cg * 4) / CKPT) * (3 * WW * 64);
 #pragma unroll
             for (int w = 0; w < WW; ++w) {
@@ -221,6 +221,7 @@ __device__ __forceinline__ void ba_bp_local_bundle(const BaDpParams &P, const Ba
                 for (int w = 0; w < WW; ++w) accA[c][w] = accB[c][w] = 0u;
             }
         }
+        if (P.no_dir) return;  // (score-only plans: the end cell is tracked above, nothing is walked)
 #pragma unroll
         for (int w = 0; w < WW; ++w) {
             *reinterpret_cast<uint4 *>(dir + ((size_t)(w * 2 + 0) * cgs + cg) * 256) =
