@@ -502,12 +502,12 @@ static int plan_build(bioalign_plan *pl, const bioalign_batch_t *in, const uint3
         pl->fkey = 0;
         if (!pl->affine) pl->K = 8;
     }
-    // Unit scoring -- every substitution score +1 or -1, gap 1: BASELINE's DNA configuration -- in global or local mode with
+    // Unit scoring -- every substitution score +1 or -1, gap 1: BASELINE's DNA configuration -- in any of the four modes, with
     // at most four column symbols and rows that fit eight words runs BIT-PARALLEL (kernels_bp.hip): same packed words,
     // same two bits per cell of traceback matrix, same records.  BIOALIGN_BITPARALLEL=0 keeps the general kernels.
     // (local mode keeps the scores bit-sliced in eight planes: no alignment can score above min(len(s1), len(s2)))
     if (!wide && !pl->affine && pl->gap == 1 && pl->nb <= 4 && wmax == 1 && max_n <= (uint64_t)ba_bp_max_rows() &&
-        (pl->mode == BIOALIGN_GLOBAL || (pl->mode == BIOALIGN_LOCAL && min_nm_max <= (uint64_t)ba_bp_max_local_score())) &&
+        (pl->mode != BIOALIGN_LOCAL || min_nm_max <= (uint64_t)ba_bp_max_local_score()) &&
         env_u64("BIOALIGN_BITPARALLEL", 1) != 0) {
         bool unit = true;
         for (int i = 0; i < pl->na * pl->nb && unit; ++i) unit = in->score_table[i] == 1 || in->score_table[i] == -1;

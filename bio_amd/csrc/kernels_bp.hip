@@ -1,11 +1,11 @@
-// kernels_bp.hip -- gfx950 (MI355X): BIT-PARALLEL global alignment for unit scoring.
+// kernels_bp.hip -- gfx950 (MI355X): BIT-PARALLEL alignment (global, local, fitting, overlap) for unit scoring.
 //
-// Scope: AlignGlobal (align.go:76-143) when every substitution score is +1 or -1 and the gap penalty is 1 --
-// BASELINE.json's DNA configuration -- with at most four column symbols and s1 of at most 256 symbols.  Everything
-// else stays on the general kernels (kernels.hip).  Same boundary, same outputs, same workspace layout sizes.
+// Scope: AlignGlobal / AlignLocal / AlignPair (align.go:76-249, align_pair.go:3-246) when every substitution score is
+// +1 or -1 and the gap penalty is 1 -- BASELINE.json's DNA configuration -- with at most four column symbols and s1 of
+// at most 256 symbols.  Everything else stays on the general kernels (kernels.hip).  Same boundary, same outputs.
 //
 // One lane = one pair, as in kernels.hip; but a lane holds a whole COLUMN of the matrix as bit vectors over the rows
-// (bit t of word t/32 = row t of the front-padded rows) and a column costs about 40 logic instructions per 32 rows
+// (bit t of word t/32 = row t of the front-padded rows) and a column costs about 20 logic instructions per 32 rows
 // instead of 3.4 (mostly half-rate) instructions per cell.
 //
 // Recurrence.  With dV(i,j) = S(i,j) - S(i-1,j) and dH(i,j) = S(i,j) - S(i,j-1), match +1, mismatch -1, gap -1:
@@ -82,11 +82,16 @@ __device__ __forceinline__ void ba_bp_build_peq(const uint32_t *s1w, const uint8
 // the time those bytes took.  Layout per bundle in the direction-word buffer (dwords, lane-interleaved):
 //     [4 symbols][WW words][64 lanes] match vectors, then [block][3 planes][WW words][64 lanes] checkpoints,
 // block b = the state BEFORE column b * CKPT + 1.
-template <int WW, int CKPT>
+// MODE: global, fitting (align_pair.go:157-166: top row free, left column -i) or overlap (align_pair.go:186-195: top
+// row -j, left column free).  The borders are the column-0 state (x = 0 where the left column costs a gap per row,
+// x = 1 where it is free) and the top border's difference handed to row 1 (ba_bp_column's top1); fitting / overlap end
+// in the leftmost strict maximum of the bottom row (align_pair.go:169-182), followed along it by its differences.
+template <int WW, int CKPT, int MODE>
 __device__ __forceinline__ void ba_bp_bundle(const BaDpParams &P, const BaBundle &B, uint32_t *peq, const uint8_t *mm,
                                              const uint8_t *code2, int lane)
 {
     static_assert(CKPT == 4 || CKPT == 8, "checkpoints every 4 or 8 columns");
+    static_assert(MODE == BA_GLOBAL || MODE == BA_FITTING || MODE == BA_OVERLAP, "local mode: ba_bp_local_bundle");
     const int n = (int)B.n, m = (int)B.m;
     const int front = WW * 32 - n;  // 0..31
     const int cgs = (m + 3) / 4;
@@ -105,8 +110,14 @@ __device__ __forceinline__ void ba_bp_bundle(const BaDpParams &P, const BaBundle
     // border's dH = gap (align.go:92-95) -- down to row 1
     uint32_t V1[WW], V2[WW], V3[WW];
 #pragma unroll
-    for (int w = 0; w < WW; ++w) V1[w] = V2[w] = V3[w] = 0u;
-    V1[0] = (1u << front) - 1u;
+    for (int w = 0; w < WW; ++w) {
+        V1[w] = MODE == BA_OVERLAP ? 0xffffffffu : 0u;  // overlap: H(i, 0) = 0, dV = 0
+        V2[w] = V3[w] = 0u;
+    }
+    if (MODE != BA_OVERLAP) V1[0] = (1u << front) - 1u;
+    const uint32_t top1 = MODE == BA_FITTING ? (1u << front) : 0u;  // fitting: H(0, j) = 0, dH = 0
+    // bottom row: S(n, 0), then one difference per column
+    int cur = MODE == BA_FITTING ? -n : 0, end_v = cur, end_j = 0;
 
     auto column_group = [&](int cg, uint32_t sw, auto full) {
         constexpr bool FULL = decltype(full)::value;
@@ -127,7 +138,13 @@ __device__ __forceinline__ void ba_bp_bundle(const BaDpParams &P, const BaBundle
                 uint32_t M[WW], oP[WW];
 #pragma unroll
                 for (int w = 0; w < WW; ++w) M[w] = pq[w * 64];
-                ba_bp_column<WW>(V1, V2, V3, M, oP);
+                const uint32_t hb = ba_bp_column<WW>(V1, V2, V3, M, oP, top1);
+                if (MODE != BA_GLOBAL) {
+                    cur += (int)hb - 1;
+                    const bool up = cur > end_v;
+                    end_v = up ? cur : end_v;
+                    end_j = up ? cg * 4 + c + 1 : end_j;
+                }
             }
         }
     };
@@ -148,9 +165,9 @@ __device__ __forceinline__ void ba_bp_bundle(const BaDpParams &P, const BaBundle
     for (int w = 0; w < WW; ++w) sum += __popc(V1[w]) + __popc(V2[w]) + __popc(V3[w]);
     if (lane < (int)B.count) {
         BaLocalBest bb;
-        bb.score = sum - front - n - m;
+        bb.score = MODE == BA_GLOBAL ? sum - front - n - m : end_v;
         bb.i = n;
-        bb.j = m;
+        bb.j = MODE == BA_GLOBAL ? m : end_j;
         bb.pad = 0;
         P.best[B.first + lane] = bb;
     }
@@ -278,12 +295,12 @@ ba_dp_bp_kernel(BaDpParams P, int max_words)
     const BaBundle B = P.bundles[b_idx];
     uint32_t *peq = lds + 128 + (size_t)wave * (4 * max_words * 64) + lane;
     const int words = ((int)B.n + 31) / 32;
-    if (words == 0) {  // no rows: global S(0, m) = -m, the walk goes left along the top border; local: the empty alignment
+    if (words == 0) {  // no rows: global S(0, m) = -m, the walk goes left along the top border; other modes: the empty alignment
         if (lane < (int)B.count) {
             BaLocalBest bb;
-            bb.score = MODE == BA_LOCAL ? 0 : -(int)B.m;
+            bb.score = MODE == BA_GLOBAL ? -(int)B.m : 0;  // (the bottom row is the top row: its leftmost maximum is column 0)
             bb.i = 0;
-            bb.j = MODE == BA_LOCAL ? 0 : (int)B.m;
+            bb.j = MODE == BA_GLOBAL ? (int)B.m : 0;
             bb.pad = 0;
             P.best[B.first + lane] = bb;
         }
@@ -293,7 +310,7 @@ ba_dp_bp_kernel(BaDpParams P, int max_words)
     case W:                                                                                        \
         if constexpr (W > WMAX) break;                                                             \
         else if constexpr (MODE == BA_LOCAL) ba_bp_local_bundle<W>(P, B, peq, mm, code2, lane);    \
-        else if constexpr (W <= 5 || CKPT == 4) ba_bp_bundle<W, CKPT>(P, B, peq, mm, code2, lane); \
+        else if constexpr (W <= 5 || CKPT == 4) ba_bp_bundle<W, CKPT, MODE>(P, B, peq, mm, code2, lane); \
         break;
     switch (words) {
         BA_BP_CASE(1)
@@ -486,14 +503,20 @@ __device__ __forceinline__ uint32_t ba_bp_pick(const uint32_t (&a)[WW], int w)
     return v;
 }
 
-template <int WW, int CKPT>
+// jstart: the column of the lane's end cell (global: m; fitting / overlap: where the DP kernel found the bottom row's
+// maximum) -- a lane joins the sweep when the wavefront reaches that column.
+template <int WW, int CKPT, int MODE>
 __device__ __forceinline__ uint32_t ba_bp_walk_bundle(const BaTraceParams &P, const BaBundle &B, uint32_t *peq,
-                                                      const uint8_t *code2, int lane, bool live)
+                                                      const uint8_t *code2, int lane, bool live, int jstart)
 {
     const int n = (int)B.n, m = (int)B.m;
     const int front = WW * 32 - n;
     const int cgs = (m + 3) / 4;
-    const int nblk = (m + CKPT - 1) / CKPT;
+    int jmax = jstart;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) jmax = max(jmax, __shfl_xor(jmax, d));
+    const int nblk = (__builtin_amdgcn_readfirstlane(jmax) + CKPT - 1) / CKPT;  // blocks right of every lane's end cell are not looked at
+    const uint32_t top1 = MODE == BA_FITTING ? (1u << front) : 0u;
     const uint32_t *ck = P.dir + B.dir_off + lane;
     const uint32_t *cs = ck + 4 * WW * 64;
     const uint32_t *s2w = P.s2w + B.s2w_off + lane;
@@ -501,7 +524,9 @@ __device__ __forceinline__ uint32_t ba_bp_walk_bundle(const BaTraceParams &P, co
 #pragma unroll
         for (int k = 0; k < 4 * WW; ++k) ba_lds_store(peq + k * 64, ck[k * 64]);
     }
-    int i = live ? n : 0;  // the row the lane is in; its column is the wavefront's
+    int i = live ? n : 0;  // the row the lane is in; its column is the wavefront's once it has joined
+    int jc = jstart;       // ... and the column of the cell it is in (for the records)
+    bool fin = false;      // fitting: the lane has reached the free top row
     BaMoveRec *recs = reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap + 1;
     uint32_t opw = 0, sh = 0, nrec = 0;
     // closes the record: `ci`, `cj` is the cell its last move arrived in
@@ -551,7 +576,7 @@ __device__ __forceinline__ uint32_t ba_bp_walk_bundle(const BaTraceParams &P, co
                 uint32_t M[WW];
 #pragma unroll
                 for (int w = 0; w < WW; ++w) M[w] = pq[w * 64];
-                ba_bp_column<WW>(V1, V2, V3, M, oP[c]);
+                ba_bp_column<WW>(V1, V2, V3, M, oP[c], top1);
 #pragma unroll
                 for (int w = 0; w < WW; ++w) oV[c][w] = V1[w];
             }
@@ -562,27 +587,34 @@ __device__ __forceinline__ uint32_t ba_bp_walk_bundle(const BaTraceParams &P, co
             constexpr int c = decltype(cc)::value;
             if (c < cols) {
                 const int j = j0 + c + 1;
-                // up while the cell came from above (align.go:105-108: the first candidate wins ties)
-                while (i > 0) {
-                    const int t = i - 1 + front;
-                    const uint32_t f = (uint32_t)t & 31u;
-                    const uint32_t x = ba_bp_pick<WW>(oV[c], t >> 5) << (31u - f);  // my row's bit on top, the rows above it below
-                    const int run = x ? __clz(x) : (int)f + 1;
-                    if (run == 0) break;
-                    ups(run, j);
-                    if (x) break;  // (else the run goes on in the word above)
+                if (j <= jstart && !fin) {
+                    // up while the cell came from above (align.go:105-108: the first candidate wins ties)
+                    while (i > 0) {
+                        const int t = i - 1 + front;
+                        const uint32_t f = (uint32_t)t & 31u;
+                        const uint32_t x = ba_bp_pick<WW>(oV[c], t >> 5) << (31u - f);  // my row's bit on top, the rows above it below
+                        const int run = x ? __clz(x) : (int)f + 1;
+                        if (run == 0) break;
+                        ups(run, j);
+                        if (x) break;  // (else the run goes on in the word above)
+                    }
+                    if (i == 0 && MODE == BA_FITTING) {  // free top row: the alignment starts here (align_pair.go:158)
+                        fin = true;
+                    } else {
+                        if (i == 0) {  // top border: left (align.go:92-95)
+                            opw |= (uint32_t)BA_MV_LEFT << sh;
+                        } else {
+                            const int t = i - 1 + front;
+                            const uint32_t pw = ba_bp_pick<WW>(oP[c], t >> 5);
+                            const uint32_t diag = (pw >> ((uint32_t)t & 31u)) & 1u;  // left unless the diagonal is strictly better
+                            opw |= (diag ? (uint32_t)BA_MV_DIAG : (uint32_t)BA_MV_LEFT) << sh;
+                            i -= (int)diag;
+                        }
+                        jc = j - 1;
+                        sh += 2;
+                        if (sh == 32) flush(i, jc);
+                    }
                 }
-                if (i == 0) {  // top border: left (align.go:92-95)
-                    opw |= (uint32_t)BA_MV_LEFT << sh;
-                } else {
-                    const int t = i - 1 + front;
-                    const uint32_t pw = ba_bp_pick<WW>(oP[c], t >> 5);
-                    const uint32_t diag = (pw >> ((uint32_t)t & 31u)) & 1u;  // left unless the diagonal is strictly better
-                    opw |= (diag ? (uint32_t)BA_MV_DIAG : (uint32_t)BA_MV_LEFT) << sh;
-                    i -= (int)diag;
-                }
-                sh += 2;
-                if (sh == 32) flush(i, j - 1);
             }
         };
         if constexpr (CKPT == 8) {
@@ -596,13 +628,13 @@ __device__ __forceinline__ uint32_t ba_bp_walk_bundle(const BaTraceParams &P, co
         walk_column(std::integral_constant<int, 1>{});
         walk_column(std::integral_constant<int, 0>{});
     }
-    ups(i, 0);  // left border: up (align.go:99-100)
+    if (MODE != BA_OVERLAP && !fin) ups(i, 0);  // left border: up (align.go:99-100); overlap: the left column is free, the alignment starts there
     const uint32_t len = nrec * 16 + (sh >> 1);
-    if (sh) flush(0, 0);
+    if (sh) flush(i, jc);
     return len;
 }
 
-template <int CKPT>
+template <int CKPT, int MODE>
 __global__ void __launch_bounds__(256) ba_trace_bp_ckpt_kernel(BaTraceParams P, int max_words)
 {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -618,10 +650,12 @@ __global__ void __launch_bounds__(256) ba_trace_bp_ckpt_kernel(BaTraceParams P, 
     const bool live = lane < (int)B.count;
     const uint32_t p = live ? P.perm[B.first + lane] : 0u;
     const int n = (int)B.n, m = (int)B.m;
+    int jstart = 0;
     if (live) {
         const BaLocalBest bb = P.best[B.first + lane];
         P.scores[p] = (int64_t)bb.score;
-        if (P.score_only && P.t_off) {  // BIOALIGN_END_CELLS: (n, m), align.go:123-124
+        jstart = bb.j;
+        if (P.score_only && P.t_off) {  // BIOALIGN_END_CELLS: (n, m), align.go:123-124; (n, leftmost maximum), align_pair.go:169-182
             P.t_off[p] = (uint64_t)bb.i;
             P.t_len[p] = (uint64_t)bb.j;
         }
@@ -632,12 +666,12 @@ __global__ void __launch_bounds__(256) ba_trace_bp_ckpt_kernel(BaTraceParams P, 
     uint32_t len = 0;
 #define BA_BP_CASE(W)                                                                                          \
     case W:                                                                                                    \
-        if constexpr (W <= 5 || CKPT == 4) len = ba_bp_walk_bundle<W, CKPT>(P, B, peq, code2, lane, live);     \
+        if constexpr (W <= 5 || CKPT == 4) len = ba_bp_walk_bundle<W, CKPT, MODE>(P, B, peq, code2, lane, live, jstart); \
         break;
     switch (words) {
-    case 0: {  // no rows: m left moves along the top border
+    case 0: {  // no rows: global, m left moves along the top border; fitting / overlap: the empty alignment
         BaMoveRec *recs = reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap + 1;
-        for (int k = 0; k < m; k += 16) {
+        for (int k = 0; MODE == BA_GLOBAL && k < m; k += 16) {
             const int count = min(16, m - k);
             BaMoveRec rr;
             rr.ops = 0x55555555u & (count >= 16 ? 0xffffffffu : ((1u << (2 * count)) - 1u));
@@ -646,7 +680,7 @@ __global__ void __launch_bounds__(256) ba_trace_bp_ckpt_kernel(BaTraceParams P, 
             rr.count = (uint32_t)count;
             if (live) recs[k / 16] = rr;
         }
-        len = (uint32_t)m;
+        len = MODE == BA_GLOBAL ? (uint32_t)m : 0u;
         break;
     }
         BA_BP_CASE(1)
@@ -695,10 +729,15 @@ extern "C" hipError_t ba_launch_dp_bp(const BaDpParams &P, int mode, int max_wor
     const int waves = 4;
     const dim3 grid((nbundles + waves - 1) / waves), block(waves * 64);
     const size_t lds = ba_dp_bp_lds_bytes(max_words, waves);
-    if (mode == BA_GLOBAL && ba_bp_ckpt(max_words) == 8)
-        hipLaunchKernelGGL((ba_dp_bp_kernel<BA_GLOBAL, 8, 5>), grid, block, lds, st, P, max_words);
-    else if (mode == BA_GLOBAL)
-        hipLaunchKernelGGL((ba_dp_bp_kernel<BA_GLOBAL, 4, 8>), grid, block, lds, st, P, max_words);
+#define BA_BP_LAUNCH_DP(M)                                                                                   \
+    if (mode == M && ba_bp_ckpt(max_words) == 8)                                                             \
+        hipLaunchKernelGGL((ba_dp_bp_kernel<M, 8, 5>), grid, block, lds, st, P, max_words);                  \
+    else if (mode == M)                                                                                      \
+        hipLaunchKernelGGL((ba_dp_bp_kernel<M, 4, 8>), grid, block, lds, st, P, max_words);
+    BA_BP_LAUNCH_DP(BA_GLOBAL)
+    else BA_BP_LAUNCH_DP(BA_FITTING)
+    else BA_BP_LAUNCH_DP(BA_OVERLAP)
+#undef BA_BP_LAUNCH_DP
     else if (mode == BA_LOCAL && max_words <= 3)
         hipLaunchKernelGGL((ba_dp_bp_kernel<BA_LOCAL, 4, 3>), grid, block, lds, st, P, max_words);
     else if (mode == BA_LOCAL && max_words <= 5)
@@ -719,12 +758,17 @@ extern "C" hipError_t ba_launch_trace_bp(const BaTraceParams &P, int mode, int m
     if (max_words < 1 || max_words > BA_BP_MAX_WORDS) return hipErrorInvalidValue;
     const int waves = 4;
     const dim3 grid((nbundles + waves - 1) / waves), block(waves * 64);
-    if (mode == BA_GLOBAL) {
+    if (mode == BA_GLOBAL || mode == BA_FITTING || mode == BA_OVERLAP) {
         const size_t lds = ba_dp_bp_lds_bytes(max_words, waves);
-        if (ba_bp_ckpt(max_words) == 8)
-            hipLaunchKernelGGL(ba_trace_bp_ckpt_kernel<8>, grid, block, lds, st, P, max_words);
-        else
-            hipLaunchKernelGGL(ba_trace_bp_ckpt_kernel<4>, grid, block, lds, st, P, max_words);
+#define BA_BP_LAUNCH_WALK(M)                                                                                 \
+    if (mode == M && ba_bp_ckpt(max_words) == 8)                                                             \
+        hipLaunchKernelGGL((ba_trace_bp_ckpt_kernel<8, M>), grid, block, lds, st, P, max_words);             \
+    else if (mode == M)                                                                                      \
+        hipLaunchKernelGGL((ba_trace_bp_ckpt_kernel<4, M>), grid, block, lds, st, P, max_words);
+        BA_BP_LAUNCH_WALK(BA_GLOBAL)
+        else BA_BP_LAUNCH_WALK(BA_FITTING)
+        else BA_BP_LAUNCH_WALK(BA_OVERLAP)
+#undef BA_BP_LAUNCH_WALK
     } else if (mode == BA_LOCAL) {
         hipLaunchKernelGGL(ba_trace_bp_kernel<true>, grid, block, (size_t)waves * 2 * BA_BP_BG * 4 * 64 * 4, st, P);
     } else {

@@ -368,7 +368,7 @@ int bioalign_plan_dp_ms(bioalign_plan *plan, float *ms, int *n_launches);
 /*
  * Which family of DP kernels the planner chose for this plan (no counterpart
  * in the reference; for benchmarks and tests): "linear", "bitparallel" (unit
- * scoring +1 / -1 / gap 1 in global mode: AlignGlobal, align.go:76), "affine"
+ * scoring +1 / -1 / gap 1: align.go:76-249, align_pair.go:3), "affine"
  * or "wide".  A static string.
  */
 const char *bioalign_plan_kernel(const bioalign_plan *plan);

@@ -1,5 +1,5 @@
-"""The bit-parallel kernels (bio_amd/csrc/kernels_bp.hip: unit scoring +1 / -1 / gap 1, global and local mode) against
-the oracle (align.go:76-143, 152-249), bit for bit on scores and both traces, and against the general kernels."""
+"""The bit-parallel kernels (bio_amd/csrc/kernels_bp.hip: unit scoring +1 / -1 / gap 1, four modes) against
+the oracle (align.go:76-143, 152-249; align_pair.go:157-195 for fitting and overlap), bit for bit on scores and both traces, and against the general kernels."""
 import random
 
 import numpy as np
@@ -28,7 +28,7 @@ def _plan_kernel(s1s, s2s, aligner, gap, mode="global"):
     return k
 
 
-MODES = ("global", "local")
+MODES = ("global", "local", "fitting", "overlap")
 A, OA = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
 
 
@@ -60,7 +60,8 @@ def test_which_plans_run_bit_parallel(monkeypatch):
     x = [b"ACGTACGTAC" * 15] * 3
     assert _plan_kernel(x, x, a, 1) == "bitparallel"
     assert _plan_kernel(x, x, a, 1, mode="local") == "bitparallel"
-    assert _plan_kernel(x, x, a, 1, mode="fitting") == "linear"
+    assert _plan_kernel(x, x, a, 1, mode="fitting") == "bitparallel"
+    assert _plan_kernel(x, x, a, 1, mode="overlap") == "bitparallel"
     assert _plan_kernel([b"ACGT" * 64], [b"ACGT" * 64], a, 1, mode="local") == "linear"  # a local score of 256 needs nine bits
     assert _plan_kernel([b"ACGT" * 64], [b"ACGT" * 63], a, 1, mode="local") == "bitparallel"
     assert _plan_kernel(x, x, a, 2) == "linear"
@@ -123,6 +124,29 @@ def test_local_end_cell_is_the_first_maximum_in_row_major_order():
     s2s += [b"ACAC" * 30, b"A" * 57, b"CA" * 41, b"AAAA"]
     assert _plan_kernel(s1s, s2s, A, 1, mode="local") == "bitparallel"
     _check("local", s1s, s2s)
+
+
+@pytest.mark.parametrize("mode", ("fitting", "overlap"))
+def test_reads_against_windows_and_overlapping_ends(mode):
+    # fitting: a short read inside a longer window (the window runs along the columns, s1 = the read is fitted whole);
+    # overlap: a suffix of one sequence against a prefix of the other -- end cells anywhere along the bottom row,
+    # including column 0, and ties along it (the leftmost strict maximum wins, align_pair.go:169-182)
+    rnd = random.Random(17)
+    s1s, s2s = [], []
+    for k in range(160):
+        read = _rand(rnd, rnd.randint(1, 120))
+        left, right = _rand(rnd, rnd.randint(0, 150)), _rand(rnd, rnd.randint(0, 150))
+        if mode == "fitting":
+            s1s.append(_edited(rnd, read, 0.1) or b"A")
+            s2s.append(left + read + right)
+        else:
+            ov = _rand(rnd, rnd.randint(0, 60))
+            s1s.append((left + ov)[-250:] or b"C")
+            s2s.append(_edited(rnd, ov, 0.08) + right)
+    s1s += [b"ACGT" * 10, b"AAAA", b"ACGT", b"G" * 40]
+    s2s += [b"ACGT" * 30, b"CCCC", b"", b"G" * 90]
+    assert _plan_kernel(s1s, s2s, A, 1, mode=mode) == "bitparallel"
+    _check(mode, s1s, s2s)
 
 
 @pytest.mark.parametrize("mode", MODES)

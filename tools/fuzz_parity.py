@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--profile", default="default", choices=sorted(SIZES), help="batch sizes and lengths to draw from")
     ap.add_argument("--fasta", action="store_true", help="the FASTA parser (both readers' rules) on random texts")
-    ap.add_argument("--unit", action="store_true", help="only what the bit-parallel kernels take: DNA / two letters, +1 / -1 / gap 1, global or local mode")
+    ap.add_argument("--unit", action="store_true", help="only what the bit-parallel kernels take: DNA / two letters, +1 / -1 / gap 1")
     ap.add_argument("--long", action="store_true", help="long mode (bioalign_long) on single pairs instead of batches")
     ap.add_argument("--stripes", type=int, default=0, help="with --long: force this many column stripes")
     ap.add_argument("--long-max", type=int, default=4000, help="with --long: largest sequence length drawn")
@@ -221,7 +221,7 @@ def main():
         if args.unit:
             if kind == "protein":
                 continue
-            name, pa, oa, gap, ext, affine, mode = "match 1 mismatch -1", bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1), 1, 1, False, ("global", "local")[int(rng.integers(0, 2))]
+            name, pa, oa, gap, ext, affine, mode = "match 1 mismatch -1", bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1), 1, 1, False, MODES[int(rng.integers(0, 4))]
         form = rng.choice(["strings", "ops", "scores", "ends"]) if not affine else rng.choice(["strings", "scores", "ends"])
         d1, o1 = pack_sequences(s1s)
         d2, o2 = pack_sequences(s2s)
