@@ -1321,7 +1321,11 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     // workgroup's bottom row stays in HBM as a checkpoint -- and then row blocks of workgroups are recomputed bottom-up
     // with residues, each from the checkpoint above it and only as far right as the walk has come, and walked at
     // once.  At most twice the cells, the traces the same as with the whole matrix (the walk is the same walk).
-    // Linear gaps, global / fitting / overlap.
+    // All four modes.  Local mode with a linear gap (align.go:216-226): the first pass leaves the maximum and the first group
+    // of rows that holds it; the first block recomputed is the one that ends with that group's workgroup, over all columns,
+    // the end cell is found in its residues, and the walk carries its exact score from block to block until it reads 0.
+    // Affine gaps (align_affine.go:12-167): the blocks hold decision words, the walk is handed from block to block as
+    // (level, cell) and, in local mode, its score; the local end cell is known after the first pass (per-row maxima).
     const uint64_t resid_all = strips * wps * 256;
     uint64_t budget = env_u64("BIOALIGN_LONG_RESIDUE_BYTES", 0);
     if (budget == 0) {
@@ -1333,9 +1337,6 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
         budget = (uint64_t)(0.7 * (double)(free_b > other ? free_b - other : 0));
     }
     const bool checkpointed = traces && resid_all > budget;
-    if (checkpointed && (affine || in->mode == BIOALIGN_LOCAL))
-        return ctx->fail(BIOALIGN_ENOMEM, "long mode: %llu bytes of traceback matrix do not fit %llu (the linear-space traceback "
-                         "covers linear gaps in global, fitting and overlap mode)", (unsigned long long)resid_all, (unsigned long long)budget);
     const uint64_t W_ = (uint64_t)ba_long_strips_per_group();
     // workgroups per recomputed block: as many as the budget holds (at least one)
     const uint64_t wgs_per_block = checkpointed ? std::max<uint64_t>(1, budget / (W_ * wps * 256)) : nsuper;
@@ -1419,15 +1420,37 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
         BaLongParams P1 = P;
         P1.no_resid = 1;
         P1.scan_only = 1;
-        le = ba_launch_long(P1, in->mode, T, K, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK, st);
+        auto launch = [&](const BaLongParams &Q, int phases) {
+            return affine ? ba_launch_long_affine(Q, in->mode, T, phases, st) : ba_launch_long(Q, in->mode, T, K, phases, st);
+        };
+        le = launch(P1, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK);
         if (le == hipSuccess) le = hipMemcpyAsync(misc, d_misc.p, 64, hipMemcpyDeviceToHost, st);
         if (le == hipSuccess) le = hipStreamSynchronize(st);
         const uint32_t *mw = reinterpret_cast<const uint32_t *>(misc);
         uint64_t ci = mw[8 + 0], cj = mw[8 + 1], done = 0;  // the cell the walk is in; moves expanded so far
         const int64_t score_seen = (int64_t)misc[1];
         const uint64_t padw = nsuper * W_ - strips;
+        const bool local = in->mode == BIOALIGN_LOCAL;
+        // local: the end cell is not known yet, only the group of rows it lies in (walk[6] = strip * 64 + lane); the
+        // blocks start with that strip's workgroup, and the first one is recomputed over all columns to find the cell
+        uint64_t hi0 = nsuper;
+        bool find_cell = false;
+        if (local && le == hipSuccess && mw[0] == 0) {
+            if (score_seen <= 0) {
+                ci = cj = 0;  // an empty alignment (align.go:222-226 returns at once)
+            } else if (affine) {
+                hi0 = ((ci - 1 + (strips * rs - n)) / rs + padw) / W_ + 1;  // the workgroup of the end cell's row
+            } else {
+                hi0 = ((uint64_t)(mw[8 + 6] >> 6) + padw) / W_ + 1;
+                find_cell = true;
+                ci = n;  // (placeholders: somewhere in the block; the kernels take the cell from the search)
+                cj = m;
+            }
+        }
+        int64_t cur_score = score_seen;  // local: the score of the cell the walk is in
+        uint32_t level = 0;              // affine: the level the walk is on (0: the middle one)
         // pass 2: row blocks bottom-up
-        for (uint64_t hi = nsuper; le == hipSuccess && mw[0] == 0 && ci > 0 && cj > 0 && hi > 0;) {
+        for (uint64_t hi = hi0; le == hipSuccess && mw[0] == 0 && ci > 0 && cj > 0 && hi > 0 && (!local || cur_score > 0 || level != 0);) {
             const uint64_t lo = hi > wgs_per_block ? hi - wgs_per_block : 0;
             const int64_t s_first = std::max<int64_t>((int64_t)(lo * W_) - (int64_t)padw, 0);
             const int64_t stop_row = lo == 0 ? 0 : (int64_t)n - (int64_t)(strips - (uint64_t)s_first) * (int64_t)rs;
@@ -1442,19 +1465,22 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
             Pb.wg_count = (uint32_t)(hi - lo);
             Pb.first_strip = (int)s_first;
             Pb.stop_row = (int)stop_row;
-            Pb.start_i = (int)ci;
-            Pb.start_j = (int)cj;
+            Pb.start_i = find_cell ? 0 : (int)ci;
+            Pb.start_j = find_cell ? -1 : (int)cj;
             Pb.trace_done = (uint32_t)done;
             Pb.trace_cap = cap;
-            le = ba_launch_long(Pb, in->mode, T, K, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK, st);
+            find_cell = false;
+            le = launch(Pb, BA_LONG_PHASE_DP | BA_LONG_PHASE_WALK);
             if (le == hipSuccess) le = hipMemcpyAsync(misc, d_misc.p, 64, hipMemcpyDeviceToHost, st);
             if (le == hipSuccess) le = hipStreamSynchronize(st);
             done += mw[8 + 2];
             ci = mw[8 + 4];
             cj = mw[8 + 5];
+            if (local) cur_score = (int64_t)(int32_t)mw[8 + 3];
+            if (affine) level = mw[8 + 6];
             hi = lo;
         }
-        if (le == hipSuccess && mw[0] == 0 && (ci > 0 || cj > 0)) {
+        if (le == hipSuccess && mw[0] == 0 && (ci > 0 || cj > 0) && !local) {
             // the walk has reached (or started on) the matrix' left or top border: what remains are the border's own moves
             // (align.go:92-100; align_pair.go:110-113, 158-159, 187-188), which the walk emits without reading a residue
             BaLongParams Pb = P;
@@ -1462,7 +1488,7 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
             Pb.start_j = (int)cj;
             Pb.trace_done = (uint32_t)done;
             Pb.trace_cap = cap;
-            le = ba_launch_long(Pb, in->mode, T, K, BA_LONG_PHASE_WALK, st);
+            le = launch(Pb, BA_LONG_PHASE_WALK);
             if (le == hipSuccess) le = hipMemcpyAsync(misc, d_misc.p, 64, hipMemcpyDeviceToHost, st);
             if (le == hipSuccess) le = hipStreamSynchronize(st);
             done += mw[8 + 2];

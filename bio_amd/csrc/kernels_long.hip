@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(1024) ba_long_local_find_kernel(BaLongParams P
         for (int r = 0; r < T && fi == 0; ++r) {
             const int i = i0 + l * T + r + 1;
             if (i < 1) continue;  // (uniform) a row above the matrix
-            const uint32_t *row = P.resid + (size_t)s * wps * 64 + l;
+            const uint32_t *row = P.resid + (size_t)(s - P.first_strip) * wps * 64 + l;  // (a recomputed block holds strips first_strip ..)
             auto rho = [&](int j) -> uint32_t {  // residue of H(i, j), j >= 0
                 if (j == 0) return 0u;
                 const int t = (j - 1) + l;
@@ -790,6 +790,7 @@ __global__ void __launch_bounds__(1024) ba_long_local_find_kernel(BaLongParams P
         P.walk[3] = (uint32_t)M;
         P.walk[4] = (uint32_t)fi;
         P.walk[5] = (uint32_t)fj;
+        P.walk[6] = bk;  // the lane group (strip * 64 + lane): the linear-space traceback recomputes the rows down to it first
         if (M > 0 && fi == 0 && !P.no_resid) atomicAdd(P.status, 1u);  // (cannot happen: some row of the group holds M)
     }
 }
@@ -842,9 +843,10 @@ __global__ void __launch_bounds__(256) ba_long_walk_kernel(BaLongParams P)
     // end cell (align.go:123-124; align_pair.go:169-182): n >= 1 and m >= 1 here
     int i = n, j = m, cur = 0, bv = 0;
     if (MODE == BA_LOCAL) {
-        // ba_long_local_find_kernel has found the end cell and written the score
-        i = (int)P.walk[0];
-        j = (int)P.walk[1];
+        // ba_long_local_find_kernel has found the end cell and written the score; a later block of the linear-space
+        // traceback goes on from the cell the host names, with the score the block below left in walk[3]
+        i = P.start_j >= 0 ? P.start_i : (int)P.walk[0];
+        j = P.start_j >= 0 ? P.start_j : (int)P.walk[1];
         cur = bv = (int)P.walk[3];
     } else if (P.start_j >= 0) {
         // the walk comes in from the stripe on the right (or the host has chosen the end cell)
@@ -1222,6 +1224,7 @@ __global__ void __launch_bounds__(256) ba_long_walk_kernel(BaLongParams P)
                 emit_run(BA_MV_DIAG, stop);
                 i -= (int)stop;
                 j -= (int)stop;
+                cur = 0;
                 break;
             }
             emit_run(BA_MV_DIAG, run);
@@ -1270,6 +1273,7 @@ __global__ void __launch_bounds__(256) ba_long_walk_kernel(BaLongParams P)
         if (fill > 0) ops[k >> 4] = (uint32_t)opacc;
         if (fill > 16) ops[(k >> 4) + 1] = (uint32_t)(opacc >> 32);
         P.walk[2] = k + fill;  // trace length
+        if (MODE == BA_LOCAL) P.walk[3] = (uint32_t)cur;  // the score of the cell the walk stopped in: 0 = the alignment's start
         P.walk[4] = (uint32_t)i;  // where the walk stopped: (0, .) or (., 0) -- the next stripe's (i, its m)
         P.walk[5] = (uint32_t)j;
         P.walk[6] = n_requests;
@@ -1343,7 +1347,10 @@ __global__ void __launch_bounds__(1024) ba_long_affine_find_kernel(BaLongParams 
     }
 }
 
-template <int MODE, int T>
+// CKPT: the walk of one recomputed row block of the linear-space traceback: the decision words of strips first_strip ..
+// are there, the walk stops on reaching row stop_row -- on whatever level it is on -- and the next block goes on from
+// (level, i, j) and, in local mode, the score V (walk[6], [4], [5], [3]).
+template <int MODE, int T, bool CKPT = false>
 __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P)
 {
     using G = BaLongGeom<T, 4>;
@@ -1367,11 +1374,20 @@ __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P
     constexpr bool top_free = (MODE == BA_LOCAL || MODE == BA_FITTING);
     constexpr bool left_free = (MODE == BA_LOCAL || MODE == BA_OVERLAP);
     const int32_t *bottom_row = P.bnd + (size_t)(P.nsuper - 1) * P.bnd_stride * 2;  // granules: low dword = hq(n, j)
+    const int first_strip = CKPT ? P.first_strip : 0, stop_row = CKPT ? P.stop_row : 0;
+    enum { LV_MM = 0, LV_G1 = 1, LV_G2 = 2 };
+    int level = LV_MM;
 
     // end cell: global (n, m) (align_pair.go:123-126); fitting / overlap the leftmost strict maximum of the bottom row's
     // true scores, from column 0 (align_pair.go:169-182); local: ba_long_affine_find_kernel has found it
     int i = n, j = m, V = 0;
-    if (MODE == BA_LOCAL) {
+    if (P.start_j >= 0) {
+        // the host names the cell (linear-space traceback: where the block below stopped, on the level it was on)
+        i = P.start_i;
+        j = P.start_j;
+        V = (int)P.walk[3];
+        level = min((int)P.walk[6], (int)LV_G2);
+    } else if (MODE == BA_LOCAL) {
         i = (int)P.walk[0];
         j = (int)P.walk[1];
         V = (int)P.walk[3];
@@ -1404,8 +1420,9 @@ __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P
     i = __builtin_amdgcn_readfirstlane(i);
     j = __builtin_amdgcn_readfirstlane(j);
     V = __builtin_amdgcn_readfirstlane(V);
+    level = __builtin_amdgcn_readfirstlane(level);
     if (tid == 0) {
-        if (MODE != BA_LOCAL) *P.score = (int64_t)V;
+        if (MODE != BA_LOCAL && P.start_j < 0) *P.score = (int64_t)V;
         P.walk[0] = (uint32_t)i;
         P.walk[1] = (uint32_t)j;
         P.walk[2] = 0;
@@ -1413,7 +1430,7 @@ __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P
         P.walk[4] = (uint32_t)i;
         P.walk[5] = (uint32_t)j;
     }
-    if (P.score_only) return;
+    if (P.score_only || P.scan_only) return;
 
     // staged decision words (the tiles of ba_long_walk_kernel)
     int tile_s = -1, tile_u = 0, ab_s = -1, ab_u = 0;
@@ -1430,7 +1447,7 @@ __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P
             uint32_t *tb = mail[6] ? buf1 : buf0;
             if (op & 1) {
                 const int sx = mail[2], tu = mail[3];
-                const uint32_t *src = P.resid + ((size_t)sx * wps + tu) * 64;
+                const uint32_t *src = P.resid + ((size_t)(sx - first_strip) * wps + tu) * 64;
                 const int words = min(TW, wps - tu);
                 constexpr int PER = (TW + 2) / 3;
                 uint32_t v[PER];
@@ -1444,7 +1461,7 @@ __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P
                 const int sx = mail[4], au = mail[5];
                 for (int x = tid - 64; x < TW; x += 192) {
                     const int uu = au + x;
-                    tb[TW * 64 + x] = uu < wps ? P.resid[((size_t)sx * wps + uu) * 64 + 63] : 0u;
+                    tb[TW * 64 + x] = uu < wps ? P.resid[((size_t)(sx - first_strip) * wps + uu) * 64 + 63] : 0u;
                 }
             }
             asm volatile("" ::: "memory");
@@ -1493,7 +1510,7 @@ __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P
             tile_s = sx;
             tile_u = window(u);
             int op = 1;
-            if (sx >= 1) {
+            if (sx - 1 >= first_strip && sx >= 1) {
                 ab_s = sx - 1;
                 ab_u = clampw(entry_word(cross_col(sx)) - TW / 2);
                 op |= 2;
@@ -1503,14 +1520,14 @@ __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P
             use_buffer(cbuf ^ 1);
         }
         pf_valid = false;
-        if (sx >= 1) {
+        if (sx - 1 >= first_strip && sx >= 1) {
             const int jc = cross_col(sx);
             pf_s = sx - 1;
             pf_tu = clampw(entry_word(jc) - (TW - 24));
             int op = 1;
             pf_as = -1;
             pf_au = 0;
-            if (sx >= 2) {
+            if (sx - 2 >= first_strip && sx >= 2) {
                 pf_as = sx - 2;
                 pf_au = clampw(entry_word(max(jc - RS, 1)) - TW / 2);
                 op |= 2;
@@ -1580,8 +1597,6 @@ __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P
         }
     };
 
-    enum { LV_MM = 0, LV_G1 = 1, LV_G2 = 2 };
-    int level = LV_MM;
     // every round stages a tile or moves: a walk that is still going after this many rounds has lost its way (cannot
     // happen with decision bits the DP wrote; the status word makes the host report it)
     int64_t rounds_left = 4 * ((int64_t)n + m) + 1024;
@@ -1591,6 +1606,7 @@ __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P
             if (lane == 0) atomicAdd(P.status, 1u);
             break;
         }
+        if (CKPT && stop_row > 0 && i <= stop_row) break;  // the rows above belong to the next block
         if (level == LV_MM) {
             if (i == 0) {  // top border: sg2 = -inf, no diagonal
                 if (top_free || j == 0) break;
@@ -1604,7 +1620,7 @@ __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P
             }
             if (MODE == BA_LOCAL && V == 0) break;  // skip-prefix cell
             const int ii = i - lane, jj = j - lane;
-            bool ok = ii >= 1 && jj >= 1;
+            bool ok = ii > stop_row && jj >= 1;
             uint32_t nib = 0;
             if (ok) nib = peek(ii, jj, ok);
             const uint64_t okmask = __ballot(ok);
@@ -1632,6 +1648,7 @@ __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P
                     emit_run(BA_MV_DIAG, stop);
                     i -= (int)stop;
                     j -= (int)stop;
+                    V = 0;
                     break;
                 }
                 if (run > 0) V -= __builtin_amdgcn_readlane(incl, (int)run - 1);
@@ -1689,7 +1706,7 @@ __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P
         } else {
             // gap in s2: (s1[i-1], gap) per move, i >= 1
             const int ii = i - lane;
-            bool ok = ii >= 1;
+            bool ok = ii > stop_row;
             bool opened = false;
             if (ok) {
                 if (ii == 1) opened = true;
@@ -1721,8 +1738,10 @@ __global__ void __launch_bounds__(256) ba_long_walk_affine_kernel(BaLongParams P
         if (fill > 0) ops[k >> 4] = (uint32_t)opacc;
         if (fill > 16) ops[(k >> 4) + 1] = (uint32_t)(opacc >> 32);
         P.walk[2] = k + fill;
+        if (MODE == BA_LOCAL) P.walk[3] = (uint32_t)V;  // 0 on the middle level: the alignment's start
         P.walk[4] = (uint32_t)i;
         P.walk[5] = (uint32_t)j;
+        P.walk[6] = (uint32_t)level;
     }
 }
 
@@ -1825,8 +1844,10 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
     }
     if (phases & BA_LONG_PHASE_WALK) {
         if constexpr (MODE == BA_LOCAL) {
-            hipLaunchKernelGGL((ba_long_local_find_kernel<T, K>), dim3(1), dim3(1024), 0, st, P);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (P.start_j < 0) {  // (a later block of the linear-space traceback: the end cell is known)
+                hipLaunchKernelGGL((ba_long_local_find_kernel<T, K>), dim3(1), dim3(1024), 0, st, P);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            }
         }
         const size_t walk_lds = (size_t)(2 * (BA_WALK_TW * 64 + BA_WALK_TW) + 8) * 4;
         if (P.first_strip || P.stop_row) {
@@ -1872,27 +1893,37 @@ static hipError_t launch_long_affine(const BaLongParams &P, int phases, hipStrea
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
     if (e != hipSuccess) return e;
     if (phases & BA_LONG_PHASE_DP) {
+        const uint32_t wgs = P.wg_count ? P.wg_count : P.nsuper - P.wg_begin;  // (a row block of the linear-space traceback, or all)
         if (P.no_resid) {  // score only: the decision words are not stored
             if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, 4, false, true, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds)) != hipSuccess)
                 return e;
-            hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, 4, false, true, true>), dim3(P.nsuper), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+            hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, 4, false, true, true>), dim3(wgs), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
         } else {
-            hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, 4, false, true>), dim3(P.nsuper), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
+            hipLaunchKernelGGL((ba_long_dp_kernel<MODE, T, 4, false, true>), dim3(wgs), dim3(64 * (BA_LONG_W + 1)), pad_lds, st, P);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (phases & BA_LONG_PHASE_WALK) {
         if constexpr (MODE == BA_LOCAL) {
-            hipLaunchKernelGGL((ba_long_affine_find_kernel<T>), dim3(1), dim3(1024), 0, st, P);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (P.start_j < 0) {  // (a block of the linear-space traceback: the end cell is known)
+                hipLaunchKernelGGL((ba_long_affine_find_kernel<T>), dim3(1), dim3(1024), 0, st, P);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            }
         }
         const size_t walk_lds = (size_t)(2 * (BA_WALK_TW * 64 + BA_WALK_TW) + 8) * 4;
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_walk_affine_kernel<MODE, T>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds)) != hipSuccess)
-            return e;
-        hipLaunchKernelGGL((ba_long_walk_affine_kernel<MODE, T>), dim3(1), dim3(256), walk_lds, st, P);
-        if ((e = hipGetLastError()) != hipSuccess || P.score_only) return e;
+        if (P.first_strip || P.stop_row) {
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_walk_affine_kernel<MODE, T, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds)) != hipSuccess)
+                return e;
+            hipLaunchKernelGGL((ba_long_walk_affine_kernel<MODE, T, true>), dim3(1), dim3(256), walk_lds, st, P);
+        } else {
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_walk_affine_kernel<MODE, T>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds)) != hipSuccess)
+                return e;
+            hipLaunchKernelGGL((ba_long_walk_affine_kernel<MODE, T>), dim3(1), dim3(256), walk_lds, st, P);
+        }
+        if ((e = hipGetLastError()) != hipSuccess || P.score_only || P.scan_only) return e;
         hipLaunchKernelGGL(ba_long_expand_kernel, dim3(1), dim3(1024), 0, st, P);
         e = hipGetLastError();
     }
@@ -1918,7 +1949,8 @@ extern "C" int ba_long_affine_rows_per_lane(void)
 extern "C" hipError_t ba_launch_long_affine(const BaLongParams &P, int mode, int T, int phases, hipStream_t st)
 {
     if (P.n == 0 || P.m == 0 || P.strips == 0 || (uint64_t)P.nsuper * BA_LONG_W < P.strips) return hipErrorInvalidValue;
-    if (P.multi || P.left_col || P.right_col || P.col0 || P.wg_begin || P.wg_count) return hipErrorInvalidValue;  // unstriped only
+    if (P.multi || P.left_col || P.right_col || P.col0) return hipErrorInvalidValue;  // unstriped only
+    if ((uint64_t)P.wg_begin + P.wg_count > P.nsuper || P.wg_begin >= P.nsuper) return hipErrorInvalidValue;
     if (P.gap < P.gap_ext || P.gap_ext < 0 || P.epoch == 0 || P.epoch >= 0x800000u) return hipErrorInvalidValue;
     switch (mode) {
     case BA_GLOBAL: return launch_long_affine_mode<BA_GLOBAL>(P, T, phases, st);

@@ -198,8 +198,8 @@ int bioalign_plan_share_pack(bioalign_plan *plan, const bioalign_plan *packed_by
  * distinct column symbols (64 with affine gaps); anything else answers BIOALIGN_EUNSUPPORTED.  A pair whose traceback
  * matrix exceeds BIOALIGN_LONG_RESIDUE_BYTES (default: 70 % of the device's free memory) is traced
  * back in linear space -- one DP pass without the matrix, then row blocks recomputed from kept
- * rows and walked bottom-up: same traces, at most twice the cells (linear gaps, global / fitting /
- * overlap; otherwise BIOALIGN_ENOMEM).  Runs on
+ * rows and walked bottom-up: same traces, at most twice the cells (every mode, linear and affine
+ * gaps).  Runs on
  * the first device of the context -- unless the traceback matrix of a pair (up to one byte per
  * cell) would not fit that device and the context holds several: the matrix is then cut into
  * column stripes, one per device in turn, each stripe's last column handed to the next in row

@@ -298,10 +298,63 @@ def test_long_linear_space_traceback(budget, monkeypatch):
     x, y = junk(780), junk(1000)
     for mode in ("global", "fitting", "overlap"):
         assert bio_amd.AlignPairLong(mode, x, y, z, 0) == O.AlignPair(mode, x, y, oz, 0), mode
-    # what the linear-space traceback does not cover says so
-    with pytest.raises(bio_amd._native.BioAlignError) as e:
-        bio_amd.AlignPairLong("local", junk(5000), junk(5000), a, 1)  # 6.5 MB of residues
-    assert e.value.code == bio_amd._native.ENOMEM
+
+
+@pytest.mark.parametrize("budget", ["1", "3000000"])
+def test_long_linear_space_traceback_local(budget, monkeypatch):
+    # local mode (align.go:152-249 on long inputs): the first pass leaves the maximum and the group of rows that holds it,
+    # the block that ends there is recomputed over all columns to find the end cell (first maximum in row-major order),
+    # and the walk carries its exact score upwards from block to block until it reads 0
+    monkeypatch.setenv("BIOALIGN_LONG_RESIDUE_BYTES", budget)
+    a, oa = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
+    rng = random.Random(11)
+    junk = lambda k: bytes(rng.choice(b"ACGT") for _ in range(k))
+    core = junk(2600)  # an alignment that crosses two block boundaries of 1024 rows
+    mut = bytearray(core)
+    for k in range(0, len(mut), 37):
+        mut[k] = rng.choice(b"ACGT")
+    del mut[700:709]
+    mut[1500:1500] = junk(6)
+    cases = [(junk(900) + core + junk(1300), junk(300) + bytes(mut) + junk(200)),  # ends mid-matrix, starts two blocks up
+             (core + junk(40), bytes(mut)),                                       # starts in row 1 / column 1
+             (junk(3000), junk(2500)),                                             # a short alignment somewhere
+             (junk(1024) + core[:64], core[:64] + junk(500)),                      # the end cell in the first rows of a block
+             (b"A" * 1500, b"C" * 2000),                                          # score 0: no alignment
+             (core[:1100], core[:1100])]                                           # the whole diagonal, every block boundary crossed
+    for x, y in cases:
+        assert bio_amd.AlignPairLong("local", x, y, a, 1) == O.AlignPair("local", x, y, oa, 1), (len(x), len(y))
+    # ties between end cells in different blocks: the first one in row-major order (BLOSUM62 as well: four-bit residues)
+    rep = junk(150)
+    x, y = junk(500) + rep + junk(1800) + rep + junk(300), junk(200) + rep + junk(100)
+    assert bio_amd.AlignPairLong("local", x, y, a, 1) == O.AlignPair("local", x, y, oa, 1)
+    prng = random.Random(3)
+    px = bytes(prng.choice(b"ARNDCQEGHILKMFPSTWYV") for _ in range(2300))
+    py = px[400:1900] + bytes(prng.choice(b"ARNDCQEGHILKMFPSTWYV") for _ in range(300))
+    assert bio_amd.AlignPairLong("local", px, py, bio_amd.Blosum62, 5) == O.AlignPair("local", px, py, O.Blosum62(), 5)
+
+
+@pytest.mark.parametrize("budget", ["1", "3000000"])
+def test_long_linear_space_traceback_affine(budget, monkeypatch):
+    # Gotoh's three levels (align_affine.go:12-167) past the memory budget: the blocks hold decision words, the walk is
+    # handed from block to block as (level, cell) -- a gap that crosses a block boundary goes on on its level -- and in
+    # local mode with its score (parity with the oracle's restatement; the reference holds no affine trace fixture)
+    monkeypatch.setenv("BIOALIGN_LONG_RESIDUE_BYTES", budget)  # 1: one workgroup (512 rows at two rows per lane) per block
+    a, oa = bio_amd.MatchAligner(1, -1), O.MatchAligner(1, -1)
+    rng = random.Random(21)
+    junk = lambda k: bytes(rng.choice(b"ACGT") for _ in range(k))
+    core = junk(1700)
+    gapped = core[:480] + core[560:1000] + junk(70) + core[1000:]  # a gap in each sequence, the first across row 512
+    cases = [(core, gapped), (junk(300) + core + junk(200), junk(100) + gapped + junk(350)), (junk(1300), junk(900)),
+             (junk(40), junk(1500)), (junk(1500), junk(40)), (core[:1030], core[:1030])]
+    for x, y in cases:
+        for mode in MODES4:
+            for go, ge in ((3, 1), (5, 0)):
+                assert bio_amd.AlignAffinePairLong(mode, x, y, a, go, ge) == O.AlignAffine(mode, x, y, oa, go, ge), (mode, go, ge, len(x), len(y))
+    prng = random.Random(4)
+    px = bytes(prng.choice(b"ARNDCQEGHILKMFPSTWYV") for _ in range(1500))
+    py = px[200:700] + px[760:1400] + bytes(prng.choice(b"ARNDCQEGHILKMFPSTWYV") for _ in range(200))
+    for mode in MODES4:
+        assert bio_amd.AlignAffinePairLong(mode, px, py, bio_amd.Blosum62, 11, 1) == O.AlignAffine(mode, px, py, O.Blosum62(), 11, 1), mode
 
 
 def test_long_score_only_stores_no_residues(monkeypatch):

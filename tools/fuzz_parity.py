@@ -144,7 +144,8 @@ def main():
         return
     if args.long:
         # long mode: four modes, linear and affine gaps, DNA / few-letter / protein alphabets; per pair one of: plain,
-        # column stripes in one launch, column stripes in host-driven row blocks, linear-space traceback (tiny budget)
+        # column stripes in one launch, column stripes in host-driven row blocks (linear gaps, not local), linear-space
+        # traceback (tiny budget; every mode and gap model)
         k = aff = 0
         variants = collections.Counter()
         al = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -190,6 +191,9 @@ def main():
                     os.environ["BIOALIGN_STRIPE_BLOCKS"] = str(int(rng.integers(1, 5)))
                 elif variant == "linear-space":
                     os.environ["BIOALIGN_LONG_RESIDUE_BYTES"] = str(int(rng.choice([1, 400_000])))
+            elif rng.integers(0, 2):  # local, affine: unstriped, with or without the whole matrix in memory
+                variant = "linear-space"
+                os.environ["BIOALIGN_LONG_RESIDUE_BYTES"] = str(int(rng.choice([1, 400_000])))
             try:
                 got = bio_amd.AlignAffinePairLong(mode, x, y, pa, gap, ge) if affine else bio_amd.AlignPairLong(mode, x, y, pa, gap)
             except _native.BioAlignError as e:
