@@ -16,7 +16,8 @@
 //   AlignPair                    (align_pair.go:3)
 //   AlignGlobalLS                (align_linear.go:9)
 //   AlignGlobalAffine            (align_affine.go:12)
-//   + AlignPairBatch, AlignAffineBatch, AlignPairLong (additive)
+//   + AlignPairBatch, AlignAffineBatch, AlignPairLong (additive), AlignLongOverlap (align_long.go:17 on
+//     overlap alignments)
 #pragma once
 #include <array>
 #include <functional>
@@ -416,6 +417,47 @@ struct AlignDist {
     }
 };
 
+namespace detail {
+// a list of sequences as bioalign_all_pairs / bioalign_all_ordered_pairs take it: the bytes back to back, n + 1 offsets,
+// one code map over the symbols that occur, the aligner's scores over those symbols
+struct PackedList {
+    std::string bytes;
+    std::vector<uint64_t> off;
+    std::array<uint8_t, 256> code{};
+    std::vector<int32_t> table;
+    bioalign_batch_t in{};
+    PackedList(const std::vector<Seq> &l, const Aligner &a, int mode, int gapOpen, int gapExtend) : off(l.size() + 1, 0)
+    {
+        std::array<bool, 256> seen{};
+        for (size_t k = 0; k < l.size(); ++k) {
+            bytes += l[k];
+            off[k + 1] = bytes.size();
+            for (unsigned char b : l[k]) seen[b] = true;
+        }
+        std::vector<uint8_t> syms;
+        for (int b = 0; b < 256; ++b)
+            if (seen[b]) code[b] = (uint8_t)syms.size(), syms.push_back((uint8_t)b);
+        const int na = syms.empty() ? 1 : (int)syms.size();
+        table.assign((size_t)na * na, 0);
+        for (size_t i = 0; i < syms.size(); ++i)
+            for (size_t j = 0; j < syms.size(); ++j) table[i * na + j] = a.Score(syms[i], syms[j]);
+        bytes.push_back(0);
+        in.s1 = (const uint8_t *)bytes.data();
+        in.s1_off = off.data();
+        in.n_pairs = l.size();
+        in.mode = mode;
+        in.score_table = table.data();
+        in.na = in.nb = na;
+        in.code1 = in.code2 = code.data();
+        in.gap_open = gapOpen;
+        in.gap_extend = gapExtend;
+        in.gap_symbol = GapSymbol;
+        in.flags = BIOALIGN_SCORE_ONLY;
+    }
+    PackedList(const PackedList &) = delete;
+};
+}  // namespace detail
+
 inline std::vector<std::vector<double>> DistanceMatrix(const std::vector<Seq> &l, const AlignDist &f)
 {
     if (l.empty()) throw std::out_of_range("index out of range [0] with length 0");  // d[0] of an empty slice
@@ -424,38 +466,10 @@ inline std::vector<std::vector<double>> DistanceMatrix(const std::vector<Seq> &l
     const int m = detail::mode_of(f.mode);
     if (m < 0) throw std::invalid_argument("unknown mode " + f.mode);
     if (n < 2) return d;
-    std::vector<uint64_t> off(n + 1, 0);
-    std::string c;
-    std::array<bool, 256> seen{};
-    for (size_t k = 0; k < n; ++k) {
-        c += l[k];
-        off[k + 1] = c.size();
-        for (unsigned char b : l[k]) seen[b] = true;
-    }
-    std::array<uint8_t, 256> code{};
-    std::vector<uint8_t> syms;
-    for (int b = 0; b < 256; ++b)
-        if (seen[b]) code[b] = (uint8_t)syms.size(), syms.push_back((uint8_t)b);
-    const int na = syms.empty() ? 1 : (int)syms.size();
-    std::vector<int32_t> table((size_t)na * na, 0);
-    for (size_t i = 0; i < syms.size(); ++i)
-        for (size_t j = 0; j < syms.size(); ++j) table[i * na + j] = f.a->Score(syms[i], syms[j]);
-    c.push_back(0);
-    bioalign_batch_t in{};
-    in.s1 = (const uint8_t *)c.data();
-    in.s1_off = off.data();
-    in.n_pairs = n;
-    in.mode = m;
-    in.score_table = table.data();
-    in.na = in.nb = na;
-    in.code1 = in.code2 = code.data();
-    in.gap_open = f.gapOpen;
-    in.gap_extend = f.gapExtend;
-    in.gap_symbol = GapSymbol;
-    in.flags = BIOALIGN_SCORE_ONLY;
+    detail::PackedList pl(l, *f.a, m, f.gapOpen, f.gapExtend);
     std::vector<int64_t> sc(n * (n - 1) / 2);
     bioalign_ctx *ctx = detail::engine();
-    const int rc = bioalign_all_pairs(ctx, &in, sc.data());
+    const int rc = bioalign_all_pairs(ctx, &pl.in, sc.data());
     if (rc != 0) throw Error(rc, bioalign_last_error(ctx));
     for (size_t i = 1; i < n; ++i)
         for (size_t j = 0; j < i; ++j) d[i][j] = d[j][i] = f.toDist(sc[i * (i - 1) / 2 + j]);
@@ -471,6 +485,72 @@ inline std::vector<std::vector<double>> DistanceMatrix(const std::vector<Seq> &l
     for (size_t i = 1; i < n; ++i)
         for (size_t j = 0; j < i; ++j) d[i][j] = d[j][i] = f(l[i], l[j]);
     return d;
+}
+
+// ---- AlignLong on overlap alignments (align_long.go:17-90) -----------------------------
+// The reference's greedy assembler finds overlaps by exact substring search (strings.Index of s's last half in t,
+// align_long.go:35-45): one read error breaks the assembly.  AlignLongOverlap keeps its merge (steps 2-4,
+// align_long.go:46-89: largest overlap first, the first one wins ties, overlaps from the merged fragment deleted by
+// swapping with the last, overlaps from the absorbed one re-pointed -- the order of that list decides the output, so
+// it is kept as the reference has it) and replaces step 1 by ONE call, bioalign_all_ordered_pairs: every ordered pair
+// of fragments aligned in "overlap" mode (suffix of s against prefix of t, align_pair.go:184-195), scores and end
+// cells only.  An overlap counts when it covers at least half a fragment of t (align_long.go:10-13) and scores at
+// least minScorePerColumn per covered column.  All fragments have the same length.  Returns the assembled string, or
+// "" if the fragments do not assemble into one.  Behaviour differs from AlignLong on purpose (overlaps may hold
+// mismatches and gaps; repeats: bio_amd/assembly.py); parity unpinned, the reference has no test of AlignLong.
+inline Seq AlignLongOverlap(std::vector<Seq> ss, const Aligner &a = MatchAligner(1, -1), int indelPenalty = 2,
+                            double minScorePerColumn = 0.8)
+{
+    const size_t n = ss.size();
+    if (n == 0) return "";
+    if (n == 1) return ss[0];
+    const size_t half = ss[0].size() / 2;
+    struct Overlap {
+        size_t si, ti;
+        long long x;  // x + half = length of t's prefix inside the overlap
+    };
+    std::vector<Overlap> overlaps;
+    {
+        detail::PackedList pl(ss, a, BIOALIGN_OVERLAP, indelPenalty, indelPenalty);
+        std::vector<int64_t> sc(n * (n - 1));
+        std::vector<uint64_t> ei(n * (n - 1)), ej(n * (n - 1));
+        bioalign_ctx *ctx = detail::engine();
+        const int rc = bioalign_all_ordered_pairs(ctx, &pl.in, sc.data(), ei.data(), ej.data());
+        if (rc != 0) throw Error(rc, bioalign_last_error(ctx));
+        for (size_t si = 0; si < n; ++si)
+            for (size_t ti = 0; ti < n; ++ti) {
+                if (ss[ti] == ss[si]) continue;  // (align_long.go:38-40; also si == ti)
+                const size_t q = si * (n - 1) + (ti < si ? ti : ti - 1);
+                const uint64_t j = ej[q];
+                if (j >= half && j > 0 && (double)sc[q] >= minScorePerColumn * (double)j)
+                    overlaps.push_back({si, ti, (long long)j - (long long)half});
+            }
+    }
+    size_t left = 0;
+    for (size_t fragments = n; fragments > 1; --fragments) {
+        long long xMax = -1;
+        size_t oMax = 0;
+        for (size_t i = 0; i < overlaps.size(); ++i) {
+            const Seq &s = ss[overlaps[i].si], &t = ss[overlaps[i].ti];
+            if (s.empty() || t.empty() || t == s) continue;
+            if (overlaps[i].x > xMax) xMax = overlaps[i].x, oMax = i;
+        }
+        if (xMax == -1) return "";
+        left = overlaps[oMax].si;
+        const size_t right = overlaps[oMax].ti;
+        ss[left] += ss[right].substr((size_t)xMax + half);
+        ss[right].clear();
+        for (size_t i = 0; i < overlaps.size();) {
+            if (overlaps[i].si == left) {
+                overlaps[i] = overlaps.back();
+                overlaps.pop_back();
+                continue;
+            }
+            if (overlaps[i].si == right) overlaps[i].si = left;
+            ++i;
+        }
+    }
+    return ss[left];
 }
 
 }  // namespace bio

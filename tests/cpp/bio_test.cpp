@@ -163,6 +163,37 @@ static void gpu_tests()
         CHECK(threw, "DistanceMatrix of an empty list panics (dna_list.go:957)");
         CHECK(bio::DistanceMatrix({"ACGT"}, bio::AlignDist("local", ham, 5)) == std::vector<std::vector<double>>{{0}}, "one sequence");
     }
+
+    // AlignLongOverlap (align_long.go:17-90 with overlap alignments for step 1): reads of 60 every 20 bases of a
+    // pseudo-random genome, out of order; error-free reads give the genome back (what AlignLong returns for them), and
+    // so do reads with a substitution in every third one, which AlignLong's exact substring search cannot assemble
+    {
+        std::string genome;
+        uint32_t lcg = 12345;
+        for (int k = 0; k < 400; ++k) {
+            lcg = lcg * 1664525u + 1013904223u;
+            genome.push_back("ACGT"[(lcg >> 24) & 3]);
+        }
+        std::vector<bio::Seq> reads;
+        for (size_t s0 = 0; s0 + 60 <= genome.size(); s0 += 20) reads.push_back(genome.substr(s0, 60));
+        std::vector<bio::Seq> shuffled;
+        for (size_t k = 0; k < reads.size(); ++k) shuffled.push_back(reads[(k * 7) % reads.size()]);  // 18 reads, 7 is coprime
+        CHECK(reads.size() == 18, "18 reads");
+        CHECK(bio::AlignLongOverlap(shuffled) == genome, "AlignLongOverlap: error-free reads assemble to the genome");
+        std::vector<bio::Seq> noisy = shuffled;
+        int errors = 0;
+        for (size_t k = 0; k < noisy.size(); k += 3) {
+            char &c = noisy[k][30 + (int)(k % 5) - 2];
+            c = c == 'A' ? 'C' : c == 'C' ? 'G' : c == 'G' ? 'T' : 'A';
+            ++errors;
+        }
+        const bio::Seq got = bio::AlignLongOverlap(noisy);
+        int diff = 0;
+        for (size_t k = 0; k < got.size() && k < genome.size(); ++k) diff += got[k] != genome[k];
+        CHECK(got.size() == genome.size() && diff <= errors, "AlignLongOverlap: reads with substitutions still assemble");
+        CHECK(bio::AlignLongOverlap({}) == "" && bio::AlignLongOverlap({"ACGT"}) == "ACGT", "AlignLongOverlap: no reads, one read (align_long.go:18-23)");
+        CHECK(bio::AlignLongOverlap({"AAAACCCC", "GGGGTTTT"}) == "", "AlignLongOverlap: nothing overlaps (align_long.go:62-64)");
+    }
 }
 
 int main(int argc, char **argv)
