@@ -1406,6 +1406,15 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     P.scan_only = 0;
     P.no_resid = no_resid ? 1 : 0;
 
+    // diagnostics: when every strip started and ended (printed below)
+    DevBuf d_stamps;
+    const bool want_stamps = env_u64("BIOALIGN_LONG_STAMPS", 0) != 0;
+    if (want_stamps) {
+        if ((rc = d_stamps.alloc(ctx, strips * 16))) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(d_stamps.p, 0, strips * 16, st));
+        P.stamps = d_stamps.as<unsigned long long>();
+    }
+
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(ctx, hipEventCreate(&e0));
     HIP_TRY(ctx, hipEventCreate(&e1));
@@ -1511,6 +1520,16 @@ int long_pair(bioalign_ctx *ctx, const bioalign_batch_t *in, bioalign_result_t *
     if (env_u64("BIOALIGN_TIMING", 0) > 1) {
         const uint32_t *mw = reinterpret_cast<const uint32_t *>(misc);
         fprintf(stderr, "bioalign_long: %.3f ms, walk: %u moves, %u tile requests, %u rounds\n", ms, mw[8 + 2], mw[8 + 6], mw[8 + 7]);
+    }
+    if (want_stamps) {
+        std::vector<unsigned long long> sv(strips * 2);
+        HIP_TRY(ctx, hipMemcpy(sv.data(), d_stamps.p, strips * 16, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (uint64_t k = 0; k < strips; ++k)
+            if (sv[2 * k]) t0 = std::min(t0, sv[2 * k]);
+        for (uint64_t k = 0; k < strips; ++k)
+            fprintf(stderr, "bioalign_long strip %llu: start %.2f us, end %.2f us\n", (unsigned long long)k,
+                    (double)(sv[2 * k] - t0) * 0.01, (double)(sv[2 * k + 1] - t0) * 0.01);
     }
     if ((uint32_t)misc[0] != 0)
         return ctx->fail(BIOALIGN_EHIP, "long mode: a strip gave up waiting for the strip above it (%u waits ran out)",

@@ -158,6 +158,8 @@ struct BaLongParams {
     // stripe order[b].x and takes its parameters from multi[order[b].x].  A stripe's last column goes to its right
     // neighbour as tagged granules {score, tag} (right_gran, [n + 1], zeroed before the launch); the neighbour's strips
     // wait for the granules of their own rows (left_gran) and copy the scores to their plain left_col for the walk.
+    unsigned long long *stamps;    // diagnostics (BIOALIGN_LONG_STAMPS=1): [strips][2] real-time counter at a strip's first step
+                                   // and behind its last one (100 MHz); null: none
     const BaLongParams *multi;
     const uint2 *order;
     const unsigned long long *left_gran;

@@ -591,6 +591,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
         };
         if (pseen < need_cols(0)) pseen = max(pseen, wait_lds(prog_in, need_cols(0)));
         asm volatile("" ::: "memory");
+        if (b == 0 && P.stamps && lane == 0) P.stamps[2 * (size_t)s] = wall_clock64();
         fetch(ohA, tinA, 0);
         scores(pwA, ohA);
         stage(pwA, tinA, ohB, tinB, pwB, 0, true);
@@ -608,6 +609,7 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     if (total_steps % CPD != 0 && store_resid)
         resid[(size_t)(total_steps / CPD) * 64] = acc >> ((CPD - total_steps % CPD) * T * K);
     // every column is final now
+    if (P.stamps && lane == 0) P.stamps[2 * (size_t)s + 1] = wall_clock64();
     const bool failed = ld(&fail_s) != 0;
     if (last_wave) {
         send(m, failed ? (epoch | POISON) : epoch);
