@@ -174,7 +174,9 @@ __device__ __forceinline__ void ba_bp_bundle(const BaDpParams &P, const BaBundle
 }
 
 // LOCAL mode (align.go:152-249): bp_column.h's ba_bp_local_column; the end cell is tracked column by column.
-template <int WW>
+// NODIR: score-only plans -- nothing is stored for a walk.  (A compile-time switch: as a run-time test inside the column
+// group it cost the five-word instance 28 more spilled registers, 1.57 -> 2.23 ms per 1M pairs.)
+template <int WW, bool NODIR>
 __device__ __forceinline__ void ba_bp_local_bundle(const BaDpParams &P, const BaBundle &B, uint32_t *peq, const uint8_t *mm,
                                                    const uint8_t *code2, int lane)
 {
@@ -238,7 +240,7 @@ __device__ __forceinline__ void ba_bp_local_bundle(const BaDpParams &P, const Ba
                 for (int w = 0; w < WW; ++w) accA[c][w] = accB[c][w] = 0u;
             }
         }
-        if (P.no_dir) return;  // (score-only plans: the end cell is tracked above, nothing is walked)
+        if (NODIR) return;  // (the end cell is tracked above, nothing is walked)
 #pragma unroll
         for (int w = 0; w < WW; ++w) {
             *reinterpret_cast<uint4 *>(dir + ((size_t)(w * 2 + 0) * cgs + cg) * 256) =
@@ -309,7 +311,10 @@ ba_dp_bp_kernel(BaDpParams P, int max_words)
 #define BA_BP_CASE(W)                                                                              \
     case W:                                                                                        \
         if constexpr (W > WMAX) break;                                                             \
-        else if constexpr (MODE == BA_LOCAL) ba_bp_local_bundle<W>(P, B, peq, mm, code2, lane);    \
+        else if constexpr (MODE == BA_LOCAL) {                                                     \
+            if (P.no_dir) ba_bp_local_bundle<W, true>(P, B, peq, mm, code2, lane);                 \
+            else ba_bp_local_bundle<W, false>(P, B, peq, mm, code2, lane);                         \
+        }                                                                                          \
         else if constexpr (W <= 5 || CKPT == 4) ba_bp_bundle<W, CKPT, MODE>(P, B, peq, mm, code2, lane); \
         break;
     switch (words) {

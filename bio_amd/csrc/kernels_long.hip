@@ -378,7 +378,9 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
     int h[T];
     // strip profile: prof[b][lane] = the scores of my T rows against column symbol b, one signed byte per row
     // (score + 2g; rows above the matrix carry the padding code: -128 against everything)
-    uint32_t *prof = dyn_lds + (size_t)w * P.nb * 64 + lane;
+    // (one row more than there are column symbols: row nb scores -128 against every row -- the columns left of the matrix
+    // that a lane passes before its first real one, see `steady` below)
+    uint32_t *prof = dyn_lds + (size_t)w * (P.nb + 1) * 64 + lane;
     int left_top = first_col(i0);  // Hs(i0, 0): the diagonal of my first row's first column
     {
         int code[T];
@@ -429,6 +431,8 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
             for (int r = 0; r < T; ++r) word |= (uint32_t)(uint8_t)tab[code[r] * P.nb + b] << (8 * r);
             prof[b * 64] = word;
         }
+        prof[P.nb * 64] = 0x80808080u;
+        L.ohw[lane] = 256u * (uint32_t)P.nb;  // the 64 columns before column 1 (block 0 reads them as its previous block's symbols)
     }
     // (checkpointed runs: the first pass stores no residues; a row block's pass stores them in the block's own buffer)
     constexpr bool store_resid = !NORES;
@@ -482,8 +486,14 @@ __global__ void __launch_bounds__(64 * (BA_LONG_W + 1)) ba_long_dp_kernel(BaLong
         const int32_t *tin_base = ring_in + (t0 & (RING - 1));
         const int32_t *tinf_base = ring_f_in + (AFF ? (t0 & (RING - 1)) : 0);
         uint32_t *resid_blk = resid + (size_t)(t0 / CPD) * 64;
-        // all lanes inside their column range for the whole block?
-        const bool steady = (b >= 1) && (t0 + 64 <= m);
+        // All lanes inside their column range for the whole block?  Linear gaps: block 0 counts too.  Lane l spends its
+        // first l steps left of the matrix, where nothing needs masking: those columns carry a symbol that scores -128
+        // against every row, so a cell there is max(up, left) = left -- in the biased space a score never falls from one
+        // row to the next (local: all of column 0 is 0) -- and the lane still holds its column-0 scores when column 1
+        // comes, with the lane above's column-0 score as that cell's diagonal.  (Worth 0.05 of 8.15 ms at 100k x 100k: the
+        // first steps of a strip are slow because it trails the strip above closely, not because of the masks,
+        // profiles/r03_notes.md.)
+        const bool steady = (AFF ? b >= 1 : true) && (t0 + 64 <= m);
         // lane 63 writes column t0 + k - 63 at step k: slots of block b-1 for k < 63, the first slot of block b for k = 63
         // (the other lanes write to the scratch row).  The slots held columns RING further left: their reader must be done.
         if (!last_wave && t0 + 1 > RING) wait_lds(cons_out, (uint32_t)(t0 + 1 - RING));
@@ -1818,7 +1828,7 @@ static hipError_t launch_long(const BaLongParams &P, int phases, hipStream_t st)
     // and it is the placement the sc1 hand-off was measured in (MI355X_MICROARCH.md, "Hand-offs measured with sc1
     // loads"); workgroups beyond the CU count queue up behind the ones they depend on
     // the strip profiles of the workgroup's waves (256 bytes per column symbol and wave), padded to 84 KB
-    const size_t prof_lds = (size_t)BA_LONG_W * (size_t)P.nb * 256;
+    const size_t prof_lds = (size_t)BA_LONG_W * (size_t)(P.nb + 1) * 256;  // (+ the row of the columns left of the matrix)
     const size_t pad_lds = std::max<size_t>(prof_lds, 84 * 1024);
     hipError_t e = hipSuccess;
     if ((phases & BA_LONG_PHASE_DP) && P.multi) {
@@ -1889,7 +1899,7 @@ static hipError_t launch_long_affine(const BaLongParams &P, int phases, hipStrea
 {
     // two hand-over rings per strip (hq and F') are 80 KB of static LDS: the padding that keeps a CU to one workgroup
     // shrinks accordingly
-    const size_t prof_lds = (size_t)BA_LONG_W * (size_t)P.nb * 256;
+    const size_t prof_lds = (size_t)BA_LONG_W * (size_t)(P.nb + 1) * 256;
     const size_t pad_lds = std::max<size_t>(prof_lds, 44 * 1024);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_long_dp_kernel<MODE, T, 4, false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);
