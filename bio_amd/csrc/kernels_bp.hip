@@ -518,9 +518,11 @@ __device__ __forceinline__ uint32_t ba_bp_walk_bundle(const BaTraceParams &P, co
     const int front = WW * 32 - n;
     const int cgs = (m + 3) / 4;
     int jmax = jstart;
+    if (MODE != BA_GLOBAL) {  // (global: every lane ends in column m)
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) jmax = max(jmax, __shfl_xor(jmax, d));
-    const int nblk = (__builtin_amdgcn_readfirstlane(jmax) + CKPT - 1) / CKPT;  // blocks right of every lane's end cell are not looked at
+        for (int d = 32; d >= 1; d >>= 1) jmax = max(jmax, __shfl_xor(jmax, d));
+    }
+    const int nblk = ((MODE == BA_GLOBAL ? m : __builtin_amdgcn_readfirstlane(jmax)) + CKPT - 1) / CKPT;  // blocks right of every lane's end cell are not looked at
     const uint32_t top1 = MODE == BA_FITTING ? (1u << front) : 0u;
     const uint32_t *ck = P.dir + B.dir_off + lane;
     const uint32_t *cs = ck + 4 * WW * 64;
@@ -592,7 +594,7 @@ __device__ __forceinline__ uint32_t ba_bp_walk_bundle(const BaTraceParams &P, co
             constexpr int c = decltype(cc)::value;
             if (c < cols) {
                 const int j = j0 + c + 1;
-                if (j <= jstart && !fin) {
+                if (MODE == BA_GLOBAL || (j <= jstart && !fin)) {  // (global: every lane walks every column)
                     // up while the cell came from above (align.go:105-108: the first candidate wins ties)
                     while (i > 0) {
                         const int t = i - 1 + front;
