@@ -411,11 +411,12 @@ def run_rank(args):
             "frac_end_to_end": round(sum(op * cells_per_pass for op in ops) / VALU_PEAK_LANE_OPS / (elapsed / args.steps), 4),
         }
         if bp and dom["kernel"].endswith("<local>"):
-            # The local bit-parallel kernel writes two bits per cell and is held by those stores as much as by its
-            # instructions (profiles/r03_notes.md: 24 % of its wave cycles in s_waitcnt, taking instructions out does
-            # not move it, the same planes written by a kernel with a quarter of the instructions reached 4.4 TB/s).
-            # It is reported against the HBM roofline -- algorithmic bytes (the two planes) over the kernel's HIP-event
-            # time, PMC traffic next to it -- with the VALU side kept as `valu`.
+            # The local bit-parallel kernel writes two bits per cell: it is reported against the HBM roofline --
+            # algorithmic bytes (the two planes) over the kernel's HIP-event time, PMC traffic next to it -- with the
+            # VALU side kept as `valu`.  Measured apart (profiles/r03_notes.md): the same kernel without its stores
+            # (score-only instance) 1.35 ms, the stores alone (tools/hbm_write.hip: 5.7 TB/s for this pattern) 1.07 ms,
+            # together 1.58 ms -- instruction issue at three wavefronts per SIMD is the larger share, the stores cost
+            # 0.2 ms on top.
             r = result["roofline"]
             r["valu"] = {"achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
                          "executed_valu_per_cell": r["executed_valu_per_cell"]}
@@ -425,7 +426,9 @@ def run_rank(args):
                       "note": "local bit-parallel kernel (32 rows per lane-op, two traceback bits stored per cell): `achieved` = "
                               "algorithmic bytes (the two planes, 0.25 B per cell) over the kernel's HIP-event time, `traffic` = "
                               "WRITE_SIZE + 2 x FETCH_SIZE per launch (PMC); the VALU side (executed lane-ops against the "
-                              "full-rate issue peak) is in `valu`; SURVEY.md 8d's per-cell lane-op count is kept as "
+                              "full-rate issue peak) is in `valu` and is the larger share of the kernel's time (without its "
+                              "stores 1.35 ms, the stores alone 1.07 ms at the 5.7 TB/s the chip takes for this pattern, "
+                              "together 1.58 ms); SURVEY.md 8d's per-cell lane-op count is kept as "
                               "frac_algorithmic and exceeds 1 because the kernel does a cell in a fraction of a lane-op"})
         ns = args.cpu_sample
         if ns < 0:  # about 10-20 s of oracle work on 16 threads
