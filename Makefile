@@ -28,7 +28,7 @@ build/kernels_wide.o: $(CSRC)/kernels_wide.hip $(CSRC)/common.h $(CSRC)/device_h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
-build/kernels_bp.o: $(CSRC)/kernels_bp.hip $(CSRC)/common.h $(CSRC)/device_helpers.h
+build/kernels_bp.o: $(CSRC)/kernels_bp.hip $(CSRC)/common.h $(CSRC)/device_helpers.h $(CSRC)/bp_column.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 

@@ -190,11 +190,11 @@ __device__ __forceinline__ void ba_bp_local_bundle(const BaDpParams &P, const Ba
     ba_bp_build_peq<WW>(s1w, mm, front, peq);
 
     // column 0: H = 0 in every row, so dV = 0 (x = 1)
-    uint32_t V1[WW], V2[WW], V3[WW], Zr[WW], H[NB][WW];
+    uint32_t V1[WW], V2[WW], V3[WW], NZ[WW], H[NB][WW];
 #pragma unroll
     for (int w = 0; w < WW; ++w) {
-        V1[w] = Zr[w] = 0xffffffffu;
-        V2[w] = V3[w] = 0u;
+        V1[w] = 0xffffffffu;
+        V2[w] = V3[w] = NZ[w] = 0u;
 #pragma unroll
         for (int k = 0; k < NB; ++k) H[k][w] = 0u;
     }
@@ -217,7 +217,7 @@ __device__ __forceinline__ void ba_bp_local_bundle(const BaDpParams &P, const Ba
                     S[k] = 0u - (((uint32_t)best >> k) & 1u);
                     T[k] = 0u - (((uint32_t)(best + 1) >> k) & 1u);
                 }
-                ba_bp_local_column<WW, NB>(V1, V2, V3, H, Zr, M, S, T, accA[c], accB[c], gt, eq);
+                ba_bp_local_column<WW, NB>(V1, V2, V3, H, NZ, M, S, T, accA[c], accB[c], gt, eq);
                 // Within a column the maximum grows by at most 1.  A row above it (gt): the new maximum, first cell =
                 // the lowest such row of this column.  Otherwise a row AT it (eq) in a higher row than the cell held
                 // so far comes first in row-major order.  (best = 0: nothing is held; every empty cell "equals" it.)
