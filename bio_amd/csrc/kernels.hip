@@ -833,19 +833,34 @@ __global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_expand_bundle_kernel(Ba
             b[(15 - k) >> 2] |= y << (((15 - k) & 3) * 8);
         }
         const uint64_t chunk = end - 16ull * (r + 1);
-        if (rr.count == 16 && (al1 || dense)) {
-            // (dense layout: 16-byte stores at whatever alignment the trace's end has -- global memory takes them)
-            const uint4 v = make_uint4(a[0], a[1], a[2], a[3]);
-            __builtin_memcpy(P.t1 + chunk, &v, 16);
-        } else {
-            for (uint32_t k = 0; k < rr.count; ++k) P.t1[chunk + 15 - k] = (uint8_t)(a[(15 - k) >> 2] >> (((15 - k) & 3) * 8));
-        }
-        if (rr.count == 16 && (al2 || dense)) {
-            const uint4 v = make_uint4(b[0], b[1], b[2], b[3]);
-            __builtin_memcpy(P.t2 + chunk, &v, 16);
-        } else {
-            for (uint32_t k = 0; k < rr.count; ++k) P.t2[chunk + 15 - k] = (uint8_t)(b[(15 - k) >> 2] >> (((15 - k) & 3) * 8));
-        }
+        // A full record is one 16-byte store.  The last record of a trace holds rr.count < 16 moves, the top rr.count bytes of
+        // its chunk: whole dwords first, then at most three single bytes (a byte per move took 19 of the 25 store
+        // instructions of a wavefront and half of the kernel's time: 1 byte per lane and instruction).
+        auto put = [&](uint8_t *t, const uint32_t (&v)[4], bool aligned) {
+            if (rr.count == 16 && (aligned || dense)) {
+                // (dense layout: 16-byte stores at whatever alignment the trace's end has -- global memory takes them)
+                const uint4 q4 = make_uint4(v[0], v[1], v[2], v[3]);
+                __builtin_memcpy(t + chunk, &q4, 16);
+            } else if (aligned || dense) {
+                const uint32_t nd = rr.count >> 2, rem = rr.count & 3u;
+#pragma unroll
+                for (int d = 3; d >= 0; --d)
+                    if ((uint32_t)(3 - d) < nd) __builtin_memcpy(t + chunk + 4 * d, &v[d], 4);
+                if (rem) {
+                    const uint32_t d = 3u - nd;  // the dword the remaining moves lie in, from its top byte down
+                    const uint32_t word = d == 3 ? v[3] : d == 2 ? v[2] : d == 1 ? v[1] : v[0];
+                    for (uint32_t k = 0; k < rem; ++k) t[chunk + 4 * d + 3 - k] = (uint8_t)(word >> ((3 - k) * 8));
+                }
+            } else {
+                for (uint32_t k = 0; k < rr.count; ++k) {
+                    const uint32_t d = (15 - k) >> 2;
+                    const uint32_t word = d == 3 ? v[3] : d == 2 ? v[2] : d == 1 ? v[1] : v[0];
+                    t[chunk + 15 - k] = (uint8_t)(word >> (((15 - k) & 3) * 8));
+                }
+            }
+        };
+        put(P.t1, a, al1);
+        put(P.t2, b, al2);
     };
 #pragma unroll
     for (int k = 0; k < BA_EXPAND_PRE; ++k) {
