@@ -82,6 +82,31 @@ __device__ __forceinline__ void ba_pack_side(const uint8_t *base, uint64_t mine,
         for (int k = 0; k < nwords; ++k) out[(size_t)k * 64] = 0u;
         return;
     }
+    // The bundle's sequences back to back in the caller's array (a batch of one shape in its own order: BASELINE's
+    // configurations): the wavefront stages the whole region with coalesced dword loads -- one round trip instead of
+    // one per 16 pairs -- and every lane cuts its own words out of it (two aligned LDS reads and an alignbit per word).
+    {
+        const uint32_t nlo = (uint32_t)__shfl_down((int)lo, 1), nhi = (uint32_t)__shfl_down((int)hi, 1);
+        const uint64_t next = ((uint64_t)nhi << 32) | nlo;
+        const bool follows = lane + 1 >= count || next == mine + (uint64_t)len;
+        const uint64_t total = (uint64_t)count * (uint64_t)len;
+        if (__all(follows) && total + 8 <= 64 * 65 * 4) {
+            const uint64_t first = (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, 0) << 32) |
+                                    (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)lo, 0)) + (uint64_t)mis;
+            const uint64_t a0 = first & ~(uint64_t)3;
+            const int sh0 = (int)(first & 3);
+            const int nd = (sh0 + (int)total + 3) / 4;  // dwords that hold the region: nothing outside them is touched
+            for (int d = lane; d < nd; d += 64) tile[d] = *reinterpret_cast<const uint32_t *>(ab + a0 + 4 * (uint64_t)d);
+            // (LDS operations of one wavefront complete in order: no barrier)
+            for (int k = 0; k < nwords; ++k) {
+                const int bb = lane * len + 4 * k - shift + sh0;  // first byte of the word, relative to a0 (may lie outside the region)
+                const int i0 = min(max(bb >> 2, 0), nd - 1), i1 = min(max((bb >> 2) + 1, 0), nd - 1);
+                const uint32_t w0 = tile[i0], w1 = tile[i1];
+                out[(size_t)k * 64] = lane < count ? __builtin_amdgcn_alignbit(w1, w0, (uint32_t)(bb & 3) * 8) : 0u;
+            }
+            return;
+        }
+    }
     for (int k0 = 0; k0 < nwords; k0 += 64) {
         const int kw = min(64, nwords - k0);
         // 16 pairs per round, so that 32 independent loads are in flight per lane
