@@ -503,12 +503,23 @@ __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
 template <int WW>
 __device__ __forceinline__ uint32_t ba_bp_pick(const uint32_t (&a)[WW], int w)
 {
-    // (masks and v_bitop3, not a chain of selects: hipcc turns the chain into an indexed load from scratch memory
-    // and the block's planes then live there)
-    uint32_t v = 0u;
+    // A tree of two-way choices on the bits of w, each ONE v_bitop3_b32 (m ? x : y) with the bit spread over the word
+    // by v_bfe_i32: 3 + (WW - 1) instructions.  (Not a chain of selects: hipcc turns `w == k ? a[k] : v` chains into an
+    // indexed load from scratch memory and the block's planes then live there; a mask per word, (w == k) ? ~0 : 0 into
+    // an OR, was 3 WW instructions.)
+    static_assert(WW >= 1 && WW <= 8, "up to eight words of rows");
+    constexpr uint32_t MUX = (BA_TA & BA_TB) | (~BA_TA & BA_TC) & 0xffu;
+    const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe(w, 0, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe(w, 1, 1),
+                   m2 = (uint32_t)__builtin_amdgcn_sbfe(w, 2, 1);
+    uint32_t t[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int k = 0; k < WW; ++k) v = ba_bitop3<(BA_TA & BA_TB) | BA_TC>(a[k], (w == k) ? 0xffffffffu : 0u, v);
-    return v;
+    for (int k = 0; k < (WW + 1) / 2; ++k) t[k] = 2 * k + 1 < WW ? ba_bitop3<MUX>(m0, a[2 * k + 1], a[2 * k]) : a[2 * k];
+    if (WW <= 2) return t[0];
+    uint32_t u[2] = {0u, 0u};
+#pragma unroll
+    for (int k = 0; k < (WW + 3) / 4; ++k) u[k] = 4 * k + 2 < WW ? ba_bitop3<MUX>(m1, t[2 * k + 1], t[2 * k]) : t[2 * k];
+    if (WW <= 4) return u[0];
+    return ba_bitop3<MUX>(m2, u[1], u[0]);
 }
 
 // jstart: the column of the lane's end cell (global: m; fitting / overlap: where the DP kernel found the bottom row's
