@@ -341,6 +341,9 @@ ba_dp_bp_kernel(BaDpParams P, int max_words)
 #define BA_BP_BG 10  // column groups per band: 40 columns, so that a diagonal through a word's 32 rows needs one load (4 / 6 / 8 / 10 groups: 0.73 / 0.69 / 0.78 / 0.61 ms)
 #endif
 
+#ifndef BA_BP_MOVES
+#define BA_BP_MOVES 4  // moves between two votes on "is any lane still in this word" (1 / 4 / 8: 0.60 / 0.57 / 0.57 ms)
+#endif
 template <bool LOCAL>
 __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
 {
@@ -439,26 +442,30 @@ __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
                     idx = j - 1 - col0;
                 }
             }
-            if (act) {
-                const int ix = max(idx, 0);  // (j == 0: nothing to look up)
-                const uint32_t a = band[ix * 64], b = band[(BW + ix) * 64];
-                const bool abit = (a & bit) != 0u, bbit = (b & bit) != 0u;
-                // align.go:105-116 / 186-202: up unless left is strictly better, left unless the diagonal is
-                uint32_t mv = !abit ? BA_MV_UP : !bbit ? BA_MV_LEFT : BA_MV_DIAG;
-                bool stop = false;
-                if (LOCAL) stop = j == 0 || (!abit && bbit);  // (0, 1): H = 0; column 0: H = 0
-                else if (j == 0) mv = BA_MV_UP;               // global: the left border's moves are forced (align.go:99-100)
-                if (stop) {
-                    done = true;
-                } else {
-                    opw |= mv << sh;
-                    sh += 2;
-                    const int di = mv != BA_MV_LEFT, dj = mv != BA_MV_UP;
-                    i -= di;
-                    j -= dj;
-                    idx -= dj;
-                    bit >>= di;
-                    if (sh == 32) flush();
+            // BA_BP_MOVES moves per vote: a lane that leaves the word or its band inside the group sits the rest of it out
+#pragma unroll
+            for (int u = 0; u < BA_BP_MOVES; ++u) {
+                if (i >= lo_i && !done && !(j >= 1 && idx < 0)) {
+                    const int ix = max(idx, 0);  // (j == 0: nothing to look up)
+                    const uint32_t a = band[ix * 64], b = band[(BW + ix) * 64];
+                    const bool abit = (a & bit) != 0u, bbit = (b & bit) != 0u;
+                    // align.go:105-116 / 186-202: up unless left is strictly better, left unless the diagonal is
+                    uint32_t mv = !abit ? BA_MV_UP : !bbit ? BA_MV_LEFT : BA_MV_DIAG;
+                    bool stop = false;
+                    if (LOCAL) stop = j == 0 || (!abit && bbit);  // (0, 1): H = 0; column 0: H = 0
+                    else if (j == 0) mv = BA_MV_UP;               // global: the left border's moves are forced (align.go:99-100)
+                    if (stop) {
+                        done = true;
+                    } else {
+                        opw |= mv << sh;
+                        sh += 2;
+                        const int di = mv != BA_MV_LEFT, dj = mv != BA_MV_UP;
+                        i -= di;
+                        j -= dj;
+                        idx -= dj;
+                        bit >>= di;
+                        if (sh == 32) flush();
+                    }
                 }
             }
         }
