@@ -426,11 +426,11 @@ __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
     // Bundles are equal-shape: every lane starts in row n, so the wavefront goes up WORD by word together (one band
     // load per word and lane, all lanes' loads in flight at once); inside a word every lane takes one move per round
     // until all have left it upwards.  The round is branch-free but for the record that fills up every 16 moves:
-    // `bit` is the lane's row inside the word, `idx` its column inside the band.
+    // `row` is the lane's row inside the word, `idx` its column inside the band.
     bool done = false;  // local: the walk has reached a cell with H = 0 (or a border, where H = 0 too)
     for (int w = (n + front - 1) >> 5; w >= 0 && n > 0; --w) {
         const int lo_i = max(32 * w + 1 - front, 1);  // first row of the word; a lane is in it while i >= lo_i
-        uint32_t bit = 1u << ((uint32_t)(i - 1 + front) & 31u);
+        uint32_t row = (uint32_t)(i - 1 + front) & 31u;  // the lane's row inside the word
         if (i >= lo_i && j >= 1) col0 = load_band(w, j - 1);
         int idx = j - 1 - col0;
         while (true) {
@@ -448,24 +448,27 @@ __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
                 if (i >= lo_i && !done && !(j >= 1 && idx < 0)) {
                     const int ix = max(idx, 0);  // (j == 0: nothing to look up)
                     const uint32_t a = band[ix * 64], b = band[(BW + ix) * 64];
-                    const bool abit = (a & bit) != 0u, bbit = (b & bit) != 0u;
+                    // the cell's two bits as integers: (0,0) up, (1,0) left, (1,1) diagonal, (0,1) stop; the move and
+                    // the steps it takes are arithmetic on them (as fast as the compare-and-select form it replaced:
+                    // the walk is not bound by its instruction count, profiles/r03_notes.md)
+                    uint32_t a1 = (a >> row) & 1u;
+                    const uint32_t b1 = (b >> row) & 1u;
                     // align.go:105-116 / 186-202: up unless left is strictly better, left unless the diagonal is
-                    uint32_t mv = !abit ? BA_MV_UP : !bbit ? BA_MV_LEFT : BA_MV_DIAG;
-                    bool stop = false;
-                    if (LOCAL) stop = j == 0 || (!abit && bbit);  // (0, 1): H = 0; column 0: H = 0
-                    else if (j == 0) mv = BA_MV_UP;               // global: the left border's moves are forced (align.go:99-100)
-                    if (stop) {
-                        done = true;
-                    } else {
-                        opw |= mv << sh;
-                        sh += 2;
-                        const int di = mv != BA_MV_LEFT, dj = mv != BA_MV_UP;
-                        i -= di;
-                        j -= dj;
-                        idx -= dj;
-                        bit >>= di;
-                        if (sh == 32) flush();
-                    }
+                    uint32_t stop = 0u;
+                    if (LOCAL) stop = (b1 & ~a1) | (uint32_t)(j == 0);  // (0, 1): H = 0; column 0: H = 0
+                    else if (j == 0) a1 = 0u;                             // global: the left border's moves are forced (align.go:99-100)
+                    const uint32_t ab = a1 & b1;
+                    const uint32_t keep = stop ^ 1u;
+                    const uint32_t mv = a1 + ab;  // BA_MV_UP = 0, BA_MV_LEFT = 1, BA_MV_DIAG = 2
+                    done = done || stop != 0u;
+                    opw |= (mv & (0u - keep)) << sh;
+                    sh += 2u * keep;
+                    const int di = (int)((1u - a1 + ab) & keep), dj = (int)(a1 & keep);
+                    i -= di;
+                    j -= dj;
+                    idx -= dj;
+                    row -= (uint32_t)di;
+                    if (sh == 32) flush();
                 }
             }
         }
