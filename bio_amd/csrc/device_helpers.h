@@ -33,6 +33,19 @@ __device__ __forceinline__ uint32_t ba_push_residue(uint32_t acc, int x)
 struct BaMoveRec {
     uint32_t ops, i, j, count;
 };
+// The records of one pair inside its bundle's block of rec_cap * 64 records, LANE-INTERLEAVED: record r of lane l lies
+// at rec_off + (r + 1) * 64 + l; r = -1 is the header (trace length, where the trace ends, pair index).  Lanes that
+// close a record in the same instruction -- a column-synchronous walk whose lanes took the same number of moves --
+// store neighbouring 16-byte slots, and the expansion's threads of 16 neighbouring pairs read 256 contiguous bytes
+// per record index (per-lane runs of records were 16-byte stores scattered over as many sectors).
+struct BaRecs {
+    BaMoveRec *base;
+    __device__ __forceinline__ BaMoveRec &operator[](int r) const { return base[((ptrdiff_t)r + 1) * 64]; }
+};
+__device__ __forceinline__ BaRecs ba_recs(const void *rec, const BaBundle &B, uint32_t lane)
+{
+    return BaRecs{const_cast<BaMoveRec *>(reinterpret_cast<const BaMoveRec *>(rec)) + B.rec_off + lane};
+}
 enum { BA_MV_UP = 0, BA_MV_LEFT = 1, BA_MV_DIAG = 2 };
 
 // ----------------------------------------------------------------------------

@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(256) ba_trace_linear_kernel(BaTraceParams P)
     // the record being filled
     // (record 0 of a pair is a header for the expansion: trace length and end, so that it need not chase
     // perm -> t_len / t_off first)
-    BaMoveRec *recs = reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap + 1;
+    const BaRecs recs = ba_recs(P.rec, B, lane);
     uint32_t opw = 0, kq = 0, rec_i = 0, rec_j = 0;
     auto record = [&](uint32_t mv) {  // the move leaves cell (i, j)
         if ((kq & 15u) == 0) {
@@ -714,7 +714,7 @@ __global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_expand_kernel(BaTracePa
     const BaBundle B = P.bundles[b_idx];
     const uint32_t q = threadIdx.x / BA_EXPAND_TPP, g16 = threadIdx.x % BA_EXPAND_TPP;
     if (q >= B.count) return;
-    const BaMoveRec *recs = reinterpret_cast<const BaMoveRec *>(P.rec) + B.rec_off + (size_t)q * B.rec_cap + 1;
+    const BaRecs recs = ba_recs(P.rec, B, q);
     const BaMoveRec hd = recs[-1];
     const uint32_t p = hd.count;
     const uint64_t len = hd.ops;
@@ -811,7 +811,7 @@ __global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_expand_bundle_kernel(Ba
     const int words1 = strips * R / 4, words2 = (m + 3) / 4;
     const int stride1 = words1 | 1, stride2 = words2 | 1;  // dwords per pair, odd
     const bool live = q < B.count;
-    const BaMoveRec *recs = reinterpret_cast<const BaMoveRec *>(P.rec) + B.rec_off + (size_t)q * B.rec_cap + 1;
+    const BaRecs recs = ba_recs(P.rec, B, q);
     BaMoveRec hd;
     hd.ops = hd.i = hd.j = hd.count = 0;
     BaMoveRec pre[BA_EXPAND_PRE];
@@ -1047,7 +1047,7 @@ __global__ void __launch_bounds__(64 * BA_EXPAND_TPP) ba_ops_emit_kernel(BaTrace
     const BaBundle B = P.bundles[b_idx];
     const uint32_t q = threadIdx.x / BA_EXPAND_TPP, g16 = threadIdx.x % BA_EXPAND_TPP;
     if (q >= B.count) return;
-    const BaMoveRec *recs = reinterpret_cast<const BaMoveRec *>(P.rec) + B.rec_off + (size_t)q * B.rec_cap + 1;
+    const BaRecs recs = ba_recs(P.rec, B, q);
     const BaMoveRec hd = recs[-1];
     const uint32_t p = hd.count;
     const uint32_t nrec = (uint32_t)(((uint64_t)hd.ops + 15) / 16);

@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256) ba_trace_bp_kernel(BaTraceParams P)
 
     const uint64_t slot = o1 + o2;
     const uint64_t cap = (uint64_t)n + (uint64_t)m;
-    BaMoveRec *recs = reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap + 1;
+    const BaRecs recs = ba_recs(P.rec, B, lane);
     // the record being filled: `sh` / 2 moves so far, 2 bits each; the cell its first move left follows from the cell
     // the walk is in now and the moves themselves, so nothing is kept per move
     uint32_t opw = 0, sh = 0, nrec = 0;
@@ -558,7 +558,7 @@ __device__ __forceinline__ uint32_t ba_bp_walk_bundle(const BaTraceParams &P, co
     int i = live ? n : 0;  // the row the lane is in; its column is the wavefront's once it has joined
     int jc = jstart;       // ... and the column of the cell it is in (for the records)
     bool fin = false;      // fitting: the lane has reached the free top row
-    BaMoveRec *recs = reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap + 1;
+    const BaRecs recs = ba_recs(P.rec, B, lane);
     uint32_t opw = 0, sh = 0, nrec = 0;
     // closes the record: `ci`, `cj` is the cell its last move arrived in
     auto flush = [&](int ci, int cj) __attribute__((always_inline)) {
@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(256) ba_trace_bp_ckpt_kernel(BaTraceParams P, 
         break;
     switch (words) {
     case 0: {  // no rows: global, m left moves along the top border; fitting / overlap: the empty alignment
-        BaMoveRec *recs = reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap + 1;
+        const BaRecs recs = ba_recs(P.rec, B, lane);
         for (int k = 0; MODE == BA_GLOBAL && k < m; k += 16) {
             const int count = min(16, m - k);
             BaMoveRec rr;
@@ -741,7 +741,7 @@ __global__ void __launch_bounds__(256) ba_trace_bp_ckpt_kernel(BaTraceParams P, 
     hd.i = (uint32_t)end;
     hd.j = (uint32_t)(end >> 32);
     hd.count = p;
-    (reinterpret_cast<BaMoveRec *>(P.rec) + B.rec_off + (size_t)lane * B.rec_cap)[0] = hd;
+    ba_recs(P.rec, B, lane)[-1] = hd;
 }
 
 // ----------------------------------------------------------------------------
