@@ -6,8 +6,9 @@ include/bioalign.h).  The only data that crosses GPUs:
 
   1. DP: the last column of a stripe -- n+1 int32 working-space scores -- goes to the rank on
      its right in ROW BLOCKS (the stripe's blocks(): a few thousand rows each, the same on every
-     rank): point-to-point send / recv per block (backend nccl = RCCL over xGMI on a GPU node;
-     gloo in the CPU test), so that rank r works on block k while rank r-1 works on block k+1.
+     rank): point-to-point isend / irecv per block, all receives posted up front (backend nccl =
+     RCCL over xGMI on a GPU node; gloo in the CPU test), so that rank r works on block k while
+     rank r-1 works on block k+1.
      No collective is involved in the data path.
   2. End cell: every rank offers the best end cell of its stretch of the bottom row
      (align_pair.go:169-182; global: the last rank's last cell, align.go:123-124); one
@@ -59,7 +60,9 @@ class GpuStripe:
         left_dev = None
         if left is not None:
             left_dev = left.to(self.dev).contiguous()
-        torch.cuda.synchronize(self.dev)  # the library works on its own stream
+            # the library works on a stream of its own: what this stream has queued for `left` (the receive, the copy)
+            # must have landed -- this stream only, not the device, and not at all for the first stripe
+            torch.cuda.current_stream(self.dev).synchronize()
         self.stripe.dp_block(k, left_dev.data_ptr() if left_dev is not None else None, right.data_ptr())
         return right.to(self.xdev)
 
@@ -107,16 +110,28 @@ def align_long_striped(mode: str, s1: bytes, s2: bytes, a, gap: int, *, group=No
     G = len(bounds) - 1
     stripe = make_stripe(mode, s1, s2, a, gap, bounds[rank], bounds[rank + 1], xdev) if rank < G else None
 
-    # 1. DP, left to right, row block by row block: while this rank works on block k its left neighbour is on k+1
+    # 1. DP, left to right, row block by row block: while this rank works on block k its left neighbour is on k+1.
+    # Every receive is posted before the first block (the blocks are the same on every rank, so the buffers are known),
+    # and a block's send is not waited for until the DP is done: a rank never stalls on a peer that is merely slow to
+    # post, only on data that is not there yet.
     if stripe is not None:
-        for k, (lo, hi) in enumerate(stripe.blocks()):
+        blocks = list(stripe.blocks())
+        lefts, recvs, sends = [], [], []
+        if rank > 0:
+            for lo, hi in blocks:
+                buf = torch.empty(hi - lo, dtype=torch.int32, device=xdev)
+                lefts.append(buf)
+                recvs.append(dist.irecv(buf, src=peer(rank - 1), group=group))
+        for k, (lo, hi) in enumerate(blocks):
             left = None
             if rank > 0:
-                left = torch.empty(hi - lo, dtype=torch.int32, device=xdev)
-                dist.recv(left, src=peer(rank - 1), group=group)
-            right = stripe.dp_block(k, left)
+                recvs[k].wait()
+                left = lefts[k]
+            right = stripe.dp_block(k, left).contiguous()
             if rank + 1 < G:
-                dist.send(right.contiguous(), dst=peer(rank + 1), group=group)
+                sends.append((dist.isend(right, dst=peer(rank + 1), group=group), right))  # (the buffer lives until the wait)
+        for req, _ in sends:
+            req.wait()
 
     # 2. the end cell: leftmost strict maximum over the stripes' offers (global: the last stripe's)
     offer = [0, 0, 0, 0]
